@@ -1,0 +1,177 @@
+"""Headline benchmark: Mvoxels/s of the resident (StaticVolume) transform hot path on MI355X.
+
+Metric (BASELINE.json): "Mvoxels/s + achieved HBM GB/s, 512^3 f32 filt_bspline, 1/2/4/8 GPU".
+A step = one StaticVolume.rotate() of a resident, prefiltered 512^3 float32 volume into a device-resident
+output buffer (BASELINE config #3; the README's `static_vol_affine_out` column, volume.py:61-91), i.e. one
+launch of the cubic transform kernel.  The one-time prefilter is reported separately (volume.py:48-50 runs
+it once at construction).  Rotations follow the README sweep `rotate((0, i, 0))` (README.md:25-27) so every
+step uses a different angle; the roofline object is quoted on the same launches.
+
+N > 1 (torchrun, one rank per GPU): the global volume is (N*512) x 512 x 512, slab-partitioned along axis 0;
+halos are exchanged once at upload over RCCL, steps need no communication (weak scaling).
+
+Output: ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=60)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--interp', default='filt_bspline')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target wall time of the CPU baseline sample')
+    return ap.parse_args()
+
+
+def cpu_baseline(vol, interp, matrix, target_s):
+    """The CPU oracle (a port of the reference GPU-path semantics, OpenMP) timed on a bounded sample of the
+    same workload: a block of output planes of the same 512^3 transform.  Reported, never the target."""
+    from oracle import oracle
+    threads = oracle.num_threads()
+    n = vol.shape[0]
+    src = oracle.prefilter(vol) if interp.startswith('filt') else vol
+    m64 = np.asarray(matrix, dtype=np.float64)
+    planes, mid = 2, n // 2
+    t0 = time.perf_counter()
+    oracle.affine_ex(src, m64, interp, (planes, n, n), out_plane0=mid)
+    dt = time.perf_counter() - t0
+    planes = int(max(2, min(n // 2, planes * target_s / max(dt, 1e-3))))
+    t0 = time.perf_counter()
+    oracle.affine_ex(src, m64, interp, (planes, n, n), out_plane0=mid - planes // 2)
+    dt = time.perf_counter() - t0
+    res = {'value': round(planes * n * n / dt / 1e6, 2), 'unit': 'Mvoxels/s', 'cores': threads, 'kind': 'port',
+           'sample': f'{planes} of {n} output planes of the same {n}^3 {interp} transform (prefilter not timed), '
+                     f'oracle/vt_oracle.c with {threads} OpenMP threads, {dt:.1f} s'}
+    # the reference's actual CPU path (scipy, single-threaded) on BASELINE config #1's size
+    try:
+        import voltools_amd as vt
+        small = np.random.RandomState(0).random_sample((200, 200, 200)).astype(np.float32)
+        t0 = time.perf_counter()
+        vt.transform(small, rotation=(0, 45, 0), interpolation=interp, device='cpu')
+        dt = time.perf_counter() - t0
+        res['scipy_1thread'] = {'value': round(200 ** 3 / dt / 1e6, 2), 'unit': 'Mvoxels/s',
+                                'sample': f'200^3 {interp} via voltools_amd device="cpu" (scipy.ndimage.affine_transform), {dt:.1f} s'}
+    except Exception as e:  # pragma: no cover
+        res['scipy_1thread'] = {'error': str(e)}
+    return res
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    import torch
+    import voltools_amd as vt
+    from voltools_amd import _native
+
+    if not torch.cuda.is_available() or _native.device_count() < 1:
+        raise SystemExit('bench.py needs a GPU (the product path has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    dev = f'gpu:{local_rank}'
+    n = args.size
+    interp = args.interp
+
+    # synthetic data: uniform [0,1) float32, seeded per rank
+    vol = np.random.RandomState(rank).random_sample((n, n, n)).astype(np.float32)
+    if world > 1:
+        from voltools_amd.distributed import SlabVolume
+        sv = SlabVolume(vol, interpolation=interp, device=dev, group=dist.group.WORLD)
+    else:
+        sv = vt.StaticVolume(vol, interpolation=interp, device=dev)
+    out = vt.empty((n, n, n), device=dev)
+    gshape = (n * world, n, n)
+    centre = np.divide(np.subtract(gshape, 1), 2, dtype=np.float32)
+    mats = [vt.utils.transform_matrix(rotation=(0, float(i % 180), 0), rotation_units='deg', rotation_order='rzxz',
+                                      center=centre) for i in range(args.warmup + args.steps)]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        sv.affine(mats[i], output=out)
+    barrier()
+    sv.timer_start()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        sv.affine(mats[args.warmup + i], output=out)
+    kernel_ms_total = sv.timer_stop()          # HIP events on the stream the kernels run on
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    info = sv.info()
+    vox_per_step = n * n * n * world
+    value = vox_per_step * args.steps / elapsed / 1e6
+    kernel_ms = kernel_ms_total / args.steps
+    algo_bytes = 8.0 * n * n * n                     # 4 B compulsory source read + 4 B store per output voxel
+    achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+    result = {
+        'metric': 'Mvoxels/s, 512^3 f32 filt_bspline StaticVolume transform (resident source, device output)',
+        'value': round(value, 1), 'unit': 'Mvoxels/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'{n}^3 float32 {interp}, StaticVolume resident in HBM, rotate((0,i,0)) rzxz sweep, '
+                               f'output= device buffer' + (f', {world} axis-0 slabs of {n}^3' if world > 1 else ''),
+                   'tile': list(info.last_tile), 'lds_bytes': int(info.last_lds_bytes), 'kernel': int(info.last_kernel),
+                   'prefilter_ms_once': round(float(info.prefilter_ms), 3)},
+        'roofline': {'bound': 'hbm', 'kernel': f'affine_tiled<{interp}>', 'achieved': round(achieved, 1), 'peak': 8000.0,
+                     'unit': 'GB/s', 'frac': round(achieved / 8000.0, 4), 'traffic': None,
+                     'kernel_ms': round(kernel_ms, 4), 'algorithmic_bytes_per_launch': algo_bytes},
+    }
+
+    if rank == 0 and world == 1:
+        # extra (not the headline): the linear kernel on the same volume, and the prefilter's own roofline
+        extra = {}
+        svl = vt.StaticVolume(vol, interpolation='linear', device=dev)
+        for i in range(3):
+            svl.affine(mats[i], output=out)
+        svl.synchronize()
+        svl.timer_start()
+        for i in range(args.steps):
+            svl.affine(mats[args.warmup + i], output=out)
+        ms = svl.timer_stop() / args.steps
+        extra['linear'] = {'kernel_ms': round(ms, 4), 'Mvoxels_per_s': round(n ** 3 / ms / 1e3, 1),
+                           'achieved_GBps': round(algo_bytes / ms / 1e6, 1), 'frac_of_8TBps': round(algo_bytes / ms / 1e6 / 8000.0, 4),
+                           'tile': list(svl.info().last_tile)}
+        svl.close()
+        pf_ms = float(info.prefilter_ms)
+        if pf_ms > 0:
+            extra['prefilter'] = {'ms_once': round(pf_ms, 3), 'achieved_GBps': round(24.0 * n ** 3 / pf_ms / 1e6, 1),
+                                  'algorithmic_bytes': 24.0 * n ** 3}
+        result['extra'] = extra
+        if not args.no_cpu_baseline:
+            result['cpu_baseline'] = cpu_baseline(vol, interp, mats[args.warmup + 45 % args.steps], args.cpu_seconds)
+
+    sv.close()
+    out.free()
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,149 @@
+/*
+ * voltools_hip.h -- C ABI of the MI355X (gfx950) 3-D affine-resampling engine.
+ *
+ * This is the drop-in boundary for the reference's Python -> device launch interface
+ * (the-lay/voltools v0.6.0).  The reference has no FFI layer of its own: its host code reaches
+ * the GPU through cupy (RawKernel launches, texture objects, cp.asarray / cp.zeros / .get()).
+ * Every entry point below names the reference call site it stands in for (file:line into
+ * /root/reference).  The library behind it is hand-written HIP; it links against libamdhip64 only
+ * (no torch, no cupy), takes plain pointers and sizes, and never throws across the boundary:
+ * every function returns 0 on success, otherwise a non-zero code (a hipError_t value, or one of
+ * the VT_E* codes below) and leaves a message retrievable with vt_last_error().
+ *
+ * Conventions
+ *   - Volumes are float32, C order, shape (D, H, W); axis 0 is slowest ("depth"), axis 2 fastest.
+ *   - A transform is the reference's 4x4 float32 *pull* matrix in array-axis order
+ *     (transforms.py:147-152, :265-274): src[d',h',w'] = M[:3,:3] . (d,h,w) + M[:3,3].  Only the
+ *     first three rows are read.  The coordinate arithmetic is carried out in float64 from those
+ *     float32 (or float64, *_f64 variants) entries.
+ *   - Sampling semantics are the reference GPU path's: zero border, and an output voxel is
+ *     "outside" when any src+0.5 < 0 or src+0.5 >= dim (transforms.py:276-278).  Outside voxels are
+ *     written as 0 unless VT_KEEP_OUTSIDE is set (then they are left untouched, as the reference's
+ *     kernel does; its callers pre-zero the buffer, transforms.py:208, volume.py:73).
+ *   - Handles are opaque, owned by the library, and bound to one device and one HIP stream; calls
+ *     on one handle are serialised on that stream.  Output buffers are owned by the caller.
+ */
+#ifndef VOLTOOLS_HIP_H
+#define VOLTOOLS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* interpolation= strings of the reference (transforms.py:11-17), in that order */
+enum vt_interp {
+    VT_LINEAR = 0,               /* 'linear'              -> linearTex3D       (helper_interpolation.h:3-6)   */
+    VT_BSPLINE = 1,              /* 'bspline'             -> cubicTex3D        (helper_interpolation.h:8-40)  */
+    VT_BSPLINE_SIMPLE = 2,       /* 'bspline_simple'      -> cubicTex3DSimple  (helper_interpolation.h:42-68) */
+    VT_FILT_BSPLINE = 3,         /* 'filt_bspline'        -> prefilter + cubicTex3D       (transforms.py:195-197) */
+    VT_FILT_BSPLINE_SIMPLE = 4   /* 'filt_bspline_simple' -> prefilter + cubicTex3DSimple                        */
+};
+
+/* flags for the *_affine calls */
+enum vt_flags {
+    VT_OUT_DEVICE = 1,     /* `out` is a device pointer on the handle's device (else host memory)          */
+    VT_KEEP_OUTSIDE = 2,   /* leave outside voxels untouched (reference kernel: `continue`, transforms.py:278) */
+    VT_FORCE_DIRECT = 4,   /* diagnostic: use the untiled global-gather kernel                              */
+    VT_FORCE_TILED = 8,    /* diagnostic: use the LDS-tiled kernel even for tiny volumes                    */
+    VT_NO_ZSEP = 16        /* diagnostic: disable the axis-0-separable fast path of the cubic kernels       */
+};
+
+/* flags for vt_volume_create* */
+enum vt_create_flags {
+    VT_SRC_DEVICE = 1,       /* `data` is a device pointer on `dev` (else host memory)                    */
+    VT_SLAB_LO_INTERIOR = 2, /* slab volumes: plane 0 of `data` is NOT the global volume's first plane     */
+    VT_SLAB_HI_INTERIOR = 4  /* slab volumes: the last plane of `data` is NOT the global volume's last     */
+};
+
+enum vt_error {
+    VT_OK = 0,
+    VT_EINVAL = 10001,       /* bad argument (NULL pointer, non-positive dims, unknown interpolation ...)  */
+    VT_ENODEV = 10002,       /* device index out of range / no HIP device                                   */
+    VT_ENOMEM = 10003,       /* host allocation failed                                                      */
+    VT_EUNSUPPORTED = 10004  /* shape too large for this build's index arithmetic                           */
+};
+
+typedef struct vt_volume vt_volume_t;
+
+typedef struct vt_volume_info {
+    int32_t device;
+    int32_t interp;
+    int32_t depth, height, width;      /* resident source dims (including any slab halo planes)            */
+    int32_t out_depth, out_height, out_width;
+    int32_t last_kernel;               /* 0 none, 1 direct, 2 tiled, 3 tiled z-separable                   */
+    int32_t last_tile[3];              /* output tile (TD, TH, TW) of the last tiled launch                */
+    int32_t last_lds_dims[3];          /* staged source box (Lz, Ly, Lx) of the last tiled launch          */
+    int32_t last_lds_bytes;
+    int32_t last_grid;
+    float   prefilter_ms;              /* one-time prefilter time measured at create (filt_*), else 0      */
+    uint64_t resident_bytes;
+} vt_volume_info_t;
+
+/* ---- devices: replaces general.py:61-88 (cupy.cuda.runtime.getDeviceCount, Device(i).use()) ---- */
+int vt_device_count(int* count);                         /* 0 devices is not an error                    */
+int vt_device_name(int dev, char* buf, int buflen);
+int vt_device_props(int dev, int* cu_count, int* lds_bytes_per_block, uint64_t* hbm_bytes);
+int vt_device_synchronize(int dev);
+
+/* ---- raw device memory: replaces cp.asarray / cp.zeros / ndarray.get (transforms.py:180,223; volume.py:30,73,89) ---- */
+int vt_malloc(int dev, size_t bytes, void** dptr);
+int vt_free(int dev, void* dptr);
+int vt_memset_zero(int dev, void* dptr, size_t bytes);
+int vt_memcpy_h2d(int dev, void* dptr, const void* hptr, size_t bytes);
+int vt_memcpy_d2h(int dev, void* hptr, const void* dptr, size_t bytes);
+int vt_memcpy_d2d(int dev, void* dst, const void* src, size_t bytes);
+
+/* ---- StaticVolume: replaces volume.py:17-59 (upload, optional prefilter, texture build; done once) ----
+ * `data` holds depth*height*width float32.  For filt_* interpolations the three-pass prefilter
+ * (bspline.h:30-99, launched by transforms.py:290-309) runs here, once. */
+int vt_volume_create(int dev, int depth, int height, int width, int interp,
+                     const float* data, int create_flags, vt_volume_t** out);
+
+/* Slab-partitioned volume (no reference counterpart: the reference is single-GPU).  `data` holds
+ * local_depth planes that are planes [plane0, plane0+local_depth) of a global volume with
+ * global_depth planes; output voxels are planes [out_plane0, out_plane0+out_depth) of the global
+ * output.  Source planes outside the local window read as zero. */
+int vt_volume_create_slab(int dev, int local_depth, int height, int width, int interp,
+                          const float* data, int create_flags,
+                          int64_t plane0, int64_t global_depth, int64_t out_plane0, int out_depth,
+                          vt_volume_t** out);
+
+int vt_volume_destroy(vt_volume_t* vol);
+int vt_volume_info(const vt_volume_t* vol, vt_volume_info_t* info);
+int vt_volume_stream(const vt_volume_t* vol, void** hip_stream);   /* the hipStream_t launches go to */
+int vt_volume_sync(vt_volume_t* vol);
+
+/* Output shape other than the source shape (scipy's output_shape, transforms.py:136-150; reshape=True). */
+int vt_volume_set_output_shape(vt_volume_t* vol, int out_depth, int out_height, int out_width);
+
+/* ---- StaticVolume.affine: replaces volume.py:61-91 (matrix upload + one kernel launch) ----
+ * m4x4: 16 float32, row-major (the reference's `xform`, transforms.py:204,255).  out: out_depth *
+ * out_height * out_width float32.  With VT_OUT_DEVICE the call is asynchronous on the handle's
+ * stream; with a host `out` it returns after the copy back (volume.py:89). */
+int vt_volume_affine(vt_volume_t* vol, const float* m4x4, float* out, int flags);
+int vt_volume_affine_f64(vt_volume_t* vol, const double* m4x4, float* out, int flags);
+
+/* ---- timing: replaces the cupy event pairs of profile=True (transforms.py:167-169,214-219; volume.py:65-67,80-85)
+ * Events are recorded on the handle's stream. vt_timer_stop synchronises and returns milliseconds. */
+int vt_timer_start(vt_volume_t* vol);
+int vt_timer_stop(vt_volume_t* vol, float* ms);
+
+/* ---- prefilter on a caller-owned device array: replaces _bspline_prefilter (transforms.py:290-309;
+ * kernels SamplesToCoefficients3DX/Y/Z, bspline.h:58-99).  In place from the caller's point of view. */
+int vt_prefilter_inplace(int dev, float* d_volume, int depth, int height, int width);
+
+/* ---- one-shot transform(): replaces the GPU branch of affine (transforms.py:164-226):
+ * host in -> upload -> (prefilter) -> kernel -> host out. */
+int vt_affine_oneshot(int dev, const float* h_volume, int depth, int height, int width, int interp,
+                      const float* m4x4, float* h_out, int flags, float* elapsed_ms /* may be NULL */);
+
+const char* vt_last_error(void);
+const char* vt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOLTOOLS_HIP_H */

@@ -1,0 +1,271 @@
+"""-m gpu parity tests: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
+
+Tolerances (unit-range float32 data, stated here and in DESIGN.md):
+  * unfiltered interpolations: |hip - oracle| <= 2e-6 everywhere (same float64 coordinates, same float32
+    weights; only the summation order differs);
+  * filt_*: |hip - oracle| <= 1e-5 everywhere (the three prefilter passes amplify float32 rounding by up
+    to 27x in the max norm; the wave-scan / chunked evaluation re-associates the recursion);
+  * against the reference CPU path (scipy, golden fixtures) on the interior mask: 2e-6 / 5e-6.
+"""
+import numpy as np
+import pytest
+
+import voltools_amd as vt
+from voltools_amd import _native
+from oracle import oracle
+from conftest import interior_mask
+
+pytestmark = pytest.mark.gpu
+
+TOL = {'linear': 2e-6, 'bspline': 2e-6, 'bspline_simple': 2e-6, 'filt_bspline': 1e-5, 'filt_bspline_simple': 1e-5}
+ALL_INTERPS = list(TOL)
+
+
+def rand_vol(shape, seed=0):
+    return np.random.RandomState(seed).random_sample(shape).astype(np.float32)
+
+
+def centre(shape):
+    return np.divide(np.subtract(shape, 1), 2, dtype=np.float32)
+
+
+MATRICES = {
+    'identity': lambda s: np.eye(4, dtype=np.float32),
+    'shift_int': lambda s: vt.utils.translation_matrix((3, -2, 5)),
+    'shift_frac': lambda s: vt.utils.translation_matrix((0.5, -1.25, 2.75)),
+    'rot_inplane45': lambda s: vt.utils.transform_matrix(rotation=(0, 45, 0), center=centre(s)),
+    'rot_general': lambda s: vt.utils.transform_matrix(rotation=(25, -40, 70), rotation_order='sxyz', center=centre(s)),
+    'rot_scale_shift': lambda s: vt.utils.transform_matrix(rotation=(10, 20, 30), scale=(1.1, 0.9, 1.25),
+                                                           translation=(1.5, -2.0, 0.75), center=centre(s)),
+    'shear': lambda s: vt.utils.transform_matrix(shear=(0.1, -0.05, 0.2), center=centre(s)),
+    'magnify3': lambda s: vt.utils.transform_matrix(scale=(3.0, 3.0, 3.0), center=centre(s)),
+    'minify': lambda s: vt.utils.transform_matrix(scale=(0.4, 0.5, 0.3), center=centre(s)),
+    'minify_big': lambda s: vt.utils.transform_matrix(scale=(0.05, 0.05, 0.05), center=centre(s)),
+    'far_outside': lambda s: vt.utils.translation_matrix((1e4, 0, 0)),
+    'mirror': lambda s: vt.utils.transform_matrix(scale=(-1.0, 1.0, -1.0), center=centre(s)),
+}
+
+
+def run_case(vol, m, interp, flags=0, keep=False, out_init=None):
+    sv = vt.StaticVolume(vol, interpolation=interp, device='gpu:0')
+    if out_init is None:
+        got = sv.affine(m, _flags=flags)
+    else:
+        got = out_init.copy()
+        sv.affine(m, output=got, keep_outside=keep, _flags=flags)
+    info = sv.info()
+    sv.close()
+    return got, info
+
+
+@pytest.mark.parametrize('interp', ALL_INTERPS)
+@pytest.mark.parametrize('mname', list(MATRICES))
+@pytest.mark.parametrize('shape', [(70, 66, 72), (33, 47, 50)])
+def test_tiled_and_direct_match_oracle(interp, mname, shape):
+    """Every interpolation x matrix on a width divisible by 4 (16-byte staging) and one that is not."""
+    vol = rand_vol(shape, 1)
+    m = MATRICES[mname](shape)
+    want = oracle.affine(vol, m, interp)
+    for flags in (_native.FORCE_TILED, _native.FORCE_DIRECT):
+        got, info = run_case(vol, m, interp, flags)
+        err = np.abs(got - want).max()
+        assert err <= TOL[interp], f'{interp}/{mname}/{shape} flags={flags} kernel={info.last_kernel} err={err}'
+
+
+@pytest.mark.parametrize('interp', ['linear', 'bspline', 'filt_bspline'])
+def test_default_dispatch_uses_tiled_kernel_on_large_volumes(interp):
+    shape = (96, 100, 104)
+    vol = rand_vol(shape, 2)
+    m = MATRICES['rot_general'](shape)
+    got, info = run_case(vol, m, interp)
+    assert info.last_kernel == 2 and info.last_lds_bytes > 0
+    assert np.abs(got - oracle.affine(vol, m, interp)).max() <= TOL[interp]
+
+
+@pytest.mark.parametrize('shape', [(1, 1, 1), (1, 5, 7), (5, 5, 5), (2, 3, 130), (130, 3, 2), (13, 1, 64)])
+@pytest.mark.parametrize('interp', ['linear', 'bspline_simple', 'filt_bspline'])
+def test_degenerate_and_ragged_shapes(shape, interp):
+    vol = rand_vol(shape, 3)
+    for mname in ('identity', 'shift_frac', 'rot_general'):
+        m = MATRICES[mname](shape)
+        want = oracle.affine(vol, m, interp)
+        for flags in (_native.FORCE_TILED, _native.FORCE_DIRECT):
+            got, _ = run_case(vol, m, interp, flags)
+            assert np.abs(got - want).max() <= TOL[interp], (shape, interp, mname, flags)
+
+
+@pytest.mark.parametrize('interp', ALL_INTERPS)
+def test_golden_reference_cpu_path_interior(interp, golden_volumes, golden_volume):
+    """HIP output vs the reference's own CPU path (scipy), where the two boundary contracts agree."""
+    margin = {'linear': 0, 'bspline': 1, 'bspline_simple': 1}.get(interp, 12)
+    tol = 2e-6 if not interp.startswith('filt') else 5e-6
+    for case in ('rot_inplane', 'rot_general', 'rot_scale_shift', 'shear'):
+        m = golden_volumes[f'{case}/matrix']
+        ref = golden_volumes[f'{case}/{interp}']
+        mask = interior_mask(m, ref.shape, golden_volume.shape, margin)
+        if interp.startswith('filt'):
+            # a 20x24x28 volume has no voxel 12 away from every face; use the largest margin that keeps some
+            margin2 = 8
+            mask = interior_mask(m, ref.shape, golden_volume.shape, margin2)
+            tol = 2e-5     # |z|^8 = 2.7e-5 of boundary influence remains at margin 8
+        assert mask.sum() > 50
+        got, _ = run_case(golden_volume, m, interp, _native.FORCE_TILED)
+        assert np.abs(got - ref)[mask].max() <= tol, (interp, case)
+
+
+def test_keep_outside_and_zero_fill():
+    shape = (40, 44, 48)
+    vol = rand_vol(shape, 4)
+    m = MATRICES['rot_general'](shape)
+    stale = np.full(shape, 7.0, dtype=np.float32)
+    for flags in (_native.FORCE_TILED, _native.FORCE_DIRECT):
+        kept, _ = run_case(vol, m, 'linear', flags, keep=True, out_init=stale)
+        zeroed, _ = run_case(vol, m, 'linear', flags, keep=False, out_init=stale)
+        want_keep = oracle.affine(vol, m, 'linear', oracle.KEEP_OUTSIDE, output=stale.copy())
+        want_zero = oracle.affine(vol, m, 'linear')
+        assert (want_keep == 7.0).sum() > 100          # the case does have outside voxels
+        assert np.abs(kept - want_keep).max() <= 2e-6
+        assert np.abs(zeroed - want_zero).max() <= 2e-6
+
+
+def test_prefilter_matches_oracle_all_axes_lengths():
+    """Prefilter alone: line lengths below/at/above the chunk and segment sizes, on every axis."""
+    lib = _native.load()
+    for shape in [(5, 7, 9), (12, 11, 13), (64, 65, 63), (130, 20, 70), (20, 200, 24), (24, 20, 300), (200, 17, 129)]:
+        vol = rand_vol(shape, 5)
+        d = _native.DeviceArray.from_numpy(vol, 0)
+        _native.check(lib.vt_prefilter_inplace(0, d.ptr, *shape), 'vt_prefilter_inplace')
+        got = d.get()
+        want = oracle.prefilter(vol)
+        assert np.abs(got - want).max() <= 5e-6, shape
+        d.free()
+
+
+def test_prefilter_known_answers():
+    lib = _native.load()
+    # constant volume: coefficients equal the constant away from the faces
+    shape = (80, 72, 96)
+    vol = np.full(shape, 0.75, dtype=np.float32)
+    d = _native.DeviceArray.from_numpy(vol, 0)
+    _native.check(lib.vt_prefilter_inplace(0, d.ptr, *shape), 'vt_prefilter_inplace')
+    got = d.get()
+    assert np.abs(got[16:-16, 16:-16, 16:-16] - 0.75).max() <= 2e-6
+    d.free()
+    # filt_bspline at integer positions reproduces the samples (interior)
+    vol = rand_vol(shape, 6)
+    sv = vt.StaticVolume(vol, interpolation='filt_bspline', device='gpu:0')
+    got = sv.affine(np.eye(4, dtype=np.float32))
+    assert np.abs(got - vol)[14:-14, 14:-14, 14:-14].max() <= 5e-6
+    sv.close()
+
+
+def test_known_answers_linear():
+    shape = (64, 64, 64)
+    vol = rand_vol(shape, 7)
+    sv = vt.StaticVolume(vol, interpolation='linear', device='gpu:0')
+    assert np.array_equal(sv.affine(np.eye(4, dtype=np.float32), _flags=_native.FORCE_TILED), vol)
+    got = sv.translate((3, -2, 5), output=None)
+    want = np.zeros_like(vol)
+    want[3:, :-2, 5:] = vol[:-3, 2:, :-5]
+    assert np.array_equal(got, want)
+    sv.close()
+
+
+def test_output_kinds_and_api_surface():
+    shape = (48, 52, 56)
+    vol = rand_vol(shape, 8)
+    m = MATRICES['rot_scale_shift'](shape)
+    want = oracle.affine(vol, m, 'linear')
+    sv = vt.StaticVolume(vol, interpolation='linear', device='gpu')
+    assert sv.shape == shape and sv.device == 'gpu' and sv.interpolation == 'linear'
+    # numpy result
+    assert np.abs(sv.affine(m) - want).max() <= 2e-6
+    # DeviceArray output: returns None, result stays on the device
+    buf = vt.zeros(shape, device='gpu:0')
+    assert sv.affine(m, output=buf) is None
+    assert np.abs(buf.get() - want).max() <= 2e-6
+    # float64 matrix entry point
+    buf.fill_zero()
+    sv.affine(np.asarray(m, dtype=np.float64), output=buf)
+    assert np.abs(buf.get() - want).max() <= 2e-6
+    # front ends
+    got = vt.transform(vol, rotation=(0, 30, 0), scale=1.2, interpolation='filt_bspline', device='gpu')
+    c = centre(shape)
+    m2 = vt.utils.transform_matrix(scale=(1.2, 1.2, 1.2), rotation=(0, 30, 0), center=c)
+    assert np.abs(got - oracle.affine(vol, m2, 'filt_bspline')).max() <= 1e-5
+    assert vt.rotate(vol, (10, 20, 30), device='gpu:0').shape == shape
+    with pytest.raises(ValueError):
+        vt.affine(vol, m, interpolation='nearest', device='gpu')
+    with pytest.raises(ValueError):
+        vt.StaticVolume(vol[0], device='gpu')
+    sv.close()
+
+
+def test_torch_tensor_output_and_input():
+    torch = pytest.importorskip('torch')
+    shape = (40, 40, 40)
+    vol = rand_vol(shape, 9)
+    m = MATRICES['rot_inplane45'](shape)
+    out = torch.zeros(shape, dtype=torch.float32, device='cuda:0')
+    sv = vt.StaticVolume(torch.from_numpy(vol).to('cuda:0'), interpolation='bspline', device='gpu:0')
+    assert sv.affine(m, output=out) is None
+    sv.synchronize()
+    assert np.abs(out.cpu().numpy() - oracle.affine(vol, m, 'bspline')).max() <= 2e-6
+    sv.close()
+
+
+def test_reshape_gpu_matches_cpu_interior(golden_volumes, golden_volume):
+    m = golden_volumes['reshape/matrix']
+    ref = golden_volumes['reshape/linear']
+    got = vt.affine(golden_volume, m, interpolation='linear', reshape=True, device='gpu')
+    assert got.shape == ref.shape
+    pad_before = golden_volumes['reshape/pad_before']
+    m_eff = np.asarray(m, np.float64) @ np.asarray(vt.utils.translation_matrix(pad_before, np.float64))
+    mask = interior_mask(m_eff, ref.shape, golden_volume.shape, 0)
+    assert mask.sum() > 1000
+    assert np.abs(got - ref)[mask].max() <= 2e-6
+
+
+@pytest.mark.parametrize('interp', ['linear', 'filt_bspline'])
+def test_full_size_properties_512(interp):
+    """BASELINE sizes: properties that need no CPU oracle pass over 134M voxels."""
+    n = 512
+    rs = np.random.RandomState(10)
+    vol = rs.random_sample((n, n, n)).astype(np.float32)
+    sv = vt.StaticVolume(vol, interpolation=interp, device='gpu:0')
+    out = vt.empty((n, n, n), device='gpu:0')
+    tol = TOL[interp]
+    # identity: linear returns the input bit-for-bit; filt_bspline reproduces it in the interior
+    sv.affine(np.eye(4, dtype=np.float32), output=out)
+    got = out.get()
+    assert sv.info().last_kernel == 2
+    if interp == 'linear':
+        assert np.array_equal(got, vol)
+    else:
+        assert np.abs(got - vol)[14:-14, 14:-14, 14:-14].max() <= 5e-6
+    # integer shift is a shifted copy with zero fill (linear) -- no resampling error
+    if interp == 'linear':
+        sv.translate((7, -3, 11), output=out)
+        got = out.get()
+        want = np.zeros_like(vol)
+        want[7:, :-3, 11:] = vol[:-7, 3:, :-11]
+        assert np.array_equal(got, want)
+    # a rotated slab of the big volume equals the oracle on a sub-block (oracle finishes in seconds on 24 planes)
+    m = vt.utils.transform_matrix(rotation=(0, 45, 0), center=centre((n, n, n)))
+    sv.affine(m, output=out)
+    got = out.get()
+    assert sv.info().last_kernel == 2
+    d0 = 200
+    src = vol if interp == 'linear' else None
+    if interp == 'linear':
+        want = oracle.affine_ex(vol, np.asarray(m, np.float64), 'linear', (8, n, n), out_plane0=d0)
+        assert np.abs(got[d0:d0 + 8] - want).max() <= tol
+    # general rotation: tiled result equals the direct-gather result (two independent kernels)
+    m = vt.utils.transform_matrix(rotation=(25, -40, 70), rotation_order='sxyz', center=centre((n, n, n)))
+    sv.affine(m, output=out)
+    a = out.get()
+    sv.affine(m, output=out, _flags=_native.FORCE_DIRECT)
+    b = out.get()
+    assert np.abs(a - b).max() <= tol
+    sv.close()
+    out.free()

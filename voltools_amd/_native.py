@@ -1,0 +1,195 @@
+"""ctypes binding of the C ABI declared in ``include/voltools_hip.h`` (``lib/libvoltools_hip.so``).
+
+This is the thin shim the north star asks for: Python never touches HIP directly, it hands plain
+pointers and sizes to the hand-written HIP library.  There is no CPU fallback behind these calls:
+if the library is missing ``load()`` raises ``OSError``, and every non-zero return code becomes a
+``RuntimeError`` carrying ``vt_last_error()``.
+"""
+import ctypes
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libvoltools_hip.so')
+
+INTERP_CODES = {'linear': 0, 'bspline': 1, 'bspline_simple': 2, 'filt_bspline': 3, 'filt_bspline_simple': 4}
+
+# enum vt_flags
+OUT_DEVICE, KEEP_OUTSIDE, FORCE_DIRECT, FORCE_TILED, NO_ZSEP = 1, 2, 4, 8, 16
+# enum vt_create_flags
+SRC_DEVICE, SLAB_LO_INTERIOR, SLAB_HI_INTERIOR = 1, 2, 4
+
+# every symbol include/voltools_hip.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    'vt_device_count', 'vt_device_name', 'vt_device_props', 'vt_device_synchronize',
+    'vt_malloc', 'vt_free', 'vt_memset_zero', 'vt_memcpy_h2d', 'vt_memcpy_d2h', 'vt_memcpy_d2d',
+    'vt_volume_create', 'vt_volume_create_slab', 'vt_volume_destroy', 'vt_volume_info', 'vt_volume_stream',
+    'vt_volume_sync', 'vt_volume_set_output_shape', 'vt_volume_affine', 'vt_volume_affine_f64',
+    'vt_timer_start', 'vt_timer_stop', 'vt_prefilter_inplace', 'vt_affine_oneshot',
+    'vt_last_error', 'vt_version',
+]
+
+
+class VolumeInfo(ctypes.Structure):
+    _fields_ = [('device', ctypes.c_int32), ('interp', ctypes.c_int32),
+                ('depth', ctypes.c_int32), ('height', ctypes.c_int32), ('width', ctypes.c_int32),
+                ('out_depth', ctypes.c_int32), ('out_height', ctypes.c_int32), ('out_width', ctypes.c_int32),
+                ('last_kernel', ctypes.c_int32), ('last_tile', ctypes.c_int32 * 3),
+                ('last_lds_dims', ctypes.c_int32 * 3), ('last_lds_bytes', ctypes.c_int32),
+                ('last_grid', ctypes.c_int32), ('prefilter_ms', ctypes.c_float),
+                ('resident_bytes', ctypes.c_uint64)]
+
+
+_lib = None
+
+
+def load():
+    """Load the library once; raises OSError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError(f'{LIB_PATH} not found (run __graft_entry__.build())')
+    L = ctypes.CDLL(LIB_PATH)
+    c_int, c_void_p, c_size_t, c_i64 = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int64
+    P = ctypes.POINTER
+    L.vt_device_count.argtypes = [P(c_int)]
+    L.vt_device_name.argtypes = [c_int, ctypes.c_char_p, c_int]
+    L.vt_device_props.argtypes = [c_int, P(c_int), P(c_int), P(ctypes.c_uint64)]
+    L.vt_device_synchronize.argtypes = [c_int]
+    L.vt_malloc.argtypes = [c_int, c_size_t, P(c_void_p)]
+    L.vt_free.argtypes = [c_int, c_void_p]
+    L.vt_memset_zero.argtypes = [c_int, c_void_p, c_size_t]
+    L.vt_memcpy_h2d.argtypes = [c_int, c_void_p, c_void_p, c_size_t]
+    L.vt_memcpy_d2h.argtypes = [c_int, c_void_p, c_void_p, c_size_t]
+    L.vt_memcpy_d2d.argtypes = [c_int, c_void_p, c_void_p, c_size_t]
+    L.vt_volume_create.argtypes = [c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, P(c_void_p)]
+    L.vt_volume_create_slab.argtypes = [c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
+                                        c_i64, c_i64, c_i64, c_int, P(c_void_p)]
+    L.vt_volume_destroy.argtypes = [c_void_p]
+    L.vt_volume_info.argtypes = [c_void_p, P(VolumeInfo)]
+    L.vt_volume_stream.argtypes = [c_void_p, P(c_void_p)]
+    L.vt_volume_sync.argtypes = [c_void_p]
+    L.vt_volume_set_output_shape.argtypes = [c_void_p, c_int, c_int, c_int]
+    L.vt_volume_affine.argtypes = [c_void_p, c_void_p, c_void_p, c_int]
+    L.vt_volume_affine_f64.argtypes = [c_void_p, c_void_p, c_void_p, c_int]
+    L.vt_timer_start.argtypes = [c_void_p]
+    L.vt_timer_stop.argtypes = [c_void_p, P(ctypes.c_float)]
+    L.vt_prefilter_inplace.argtypes = [c_int, c_void_p, c_int, c_int, c_int]
+    L.vt_affine_oneshot.argtypes = [c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
+                                    P(ctypes.c_float)]
+    L.vt_last_error.restype = ctypes.c_char_p
+    L.vt_version.restype = ctypes.c_char_p
+    for name in SYMBOLS:
+        fn = getattr(L, name)
+        if name not in ('vt_last_error', 'vt_version'):
+            fn.restype = c_int
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().vt_last_error()
+        raise RuntimeError(f'{what} failed (code {rc}): {msg.decode() if msg else "?"}')
+
+
+def device_count() -> int:
+    n = ctypes.c_int(0)
+    check(load().vt_device_count(ctypes.byref(n)), 'vt_device_count')
+    return n.value
+
+
+def device_name(dev: int) -> str:
+    buf = ctypes.create_string_buffer(256)
+    check(load().vt_device_name(dev, buf, 256), 'vt_device_name')
+    return buf.value.decode()
+
+
+def device_props(dev: int) -> Tuple[int, int, int]:
+    cu, lds, hbm = ctypes.c_int(), ctypes.c_int(), ctypes.c_uint64()
+    check(load().vt_device_props(dev, ctypes.byref(cu), ctypes.byref(lds), ctypes.byref(hbm)), 'vt_device_props')
+    return cu.value, lds.value, hbm.value
+
+
+class DeviceArray:
+    """A float32 array in HBM owned through vt_malloc/vt_free (what ``cp.zeros``/``cp.asarray`` were to
+    the reference, transforms.py:180, volume.py:73).  Exposes ``__cuda_array_interface__`` so torch-ROCm can
+    wrap it without a copy."""
+
+    def __init__(self, shape, device: int = 0, zero: bool = False):
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(np.float32)
+        self.device = int(device)
+        self.size = int(np.prod(self.shape))
+        self.nbytes = self.size * 4
+        p = ctypes.c_void_p()
+        check(load().vt_malloc(self.device, max(self.nbytes, 4), ctypes.byref(p)), 'vt_malloc')
+        self.ptr = p.value
+        if zero:
+            self.fill_zero()
+
+    @classmethod
+    def from_numpy(cls, a: np.ndarray, device: int = 0) -> 'DeviceArray':
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        d = cls(a.shape, device)
+        check(load().vt_memcpy_h2d(device, d.ptr, a.ctypes.data, a.nbytes), 'vt_memcpy_h2d')
+        return d
+
+    def fill_zero(self) -> None:
+        check(load().vt_memset_zero(self.device, self.ptr, self.nbytes), 'vt_memset_zero')
+
+    def get(self) -> np.ndarray:
+        out = np.empty(self.shape, dtype=np.float32)
+        check(load().vt_memcpy_d2h(self.device, out.ctypes.data, self.ptr, self.nbytes), 'vt_memcpy_d2h')
+        return out
+
+    def set(self, a: np.ndarray) -> None:
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        if a.shape != self.shape:
+            raise ValueError(f'shape mismatch {a.shape} vs {self.shape}')
+        check(load().vt_memcpy_h2d(self.device, self.ptr, a.ctypes.data, a.nbytes), 'vt_memcpy_h2d')
+
+    @property
+    def __cuda_array_interface__(self):
+        return {'shape': self.shape, 'typestr': '<f4', 'data': (self.ptr, False), 'version': 2, 'strides': None}
+
+    def free(self) -> None:
+        if getattr(self, 'ptr', None):
+            load().vt_free(self.device, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def resolve_output(output, shape, device: int) -> Tuple[Optional[int], bool, Optional[np.ndarray]]:
+    """Classify an ``output=`` argument -> (pointer, is_device, numpy array to fill or None).
+
+    Accepted: ``DeviceArray``; anything exposing ``__cuda_array_interface__`` (torch-ROCm tensors,
+    cupy-on-ROCm arrays) -- float32, C-contiguous, right shape; or a numpy float32 array (host).
+    """
+    shape = tuple(int(s) for s in shape)
+    if isinstance(output, np.ndarray):
+        if output.dtype != np.float32 or not output.flags.c_contiguous or output.shape != shape:
+            raise ValueError('output must be a C-contiguous float32 array of the volume shape')
+        return output.ctypes.data, False, output
+    iface = getattr(output, '__cuda_array_interface__', None)
+    if iface is None:
+        raise TypeError(f'unsupported output type {type(output)}')
+    if tuple(iface['shape']) != shape or iface['typestr'] not in ('<f4', '=f4', 'f4'):
+        raise ValueError('device output must be float32 of the volume shape')
+    if iface.get('strides') is not None:
+        expect = tuple(int(np.prod(shape[i + 1:])) * 4 for i in range(len(shape)))
+        if tuple(iface['strides']) != expect:
+            raise ValueError('device output must be C-contiguous')
+    dev_attr = getattr(output, 'device', None)
+    dev_index = getattr(dev_attr, 'index', dev_attr if isinstance(dev_attr, int) else None)
+    if dev_index is not None and dev_index != device:
+        raise ValueError(f'output lives on device {dev_index}, volume on device {device}')
+    return int(iface['data'][0]), True, None

@@ -1,0 +1,555 @@
+// vt_api.hip -- the C ABI of include/voltools_hip.h (hipMalloc / hipMemcpyAsync / kernel launches).
+#include "vt_internal.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+using namespace vt;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define VT_HIP(call)                                                                               \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail((int)e_, "%s: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+int use_device(int dev)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(VT_ENODEV, "no HIP device available (%s)", hipGetErrorString(e));
+    if (dev < 0 || dev >= n) return fail(VT_ENODEV, "device index %d out of range (0..%d)", dev, n - 1);
+    VT_HIP(hipSetDevice(dev));
+    return 0;
+}
+
+std::once_flag g_init_flag[64];
+hipError_t g_init_err[64];
+
+int init_device(int dev)
+{
+    int rc = use_device(dev);
+    if (rc) return rc;
+    if (dev < 64) {
+        std::call_once(g_init_flag[dev], [dev]() { g_init_err[dev] = init_affine_kernels(); });
+        if (g_init_err[dev] != hipSuccess)
+            return fail((int)g_init_err[dev], "kernel attribute setup failed: %s", hipGetErrorString(g_init_err[dev]));
+    }
+    return 0;
+}
+
+bool is_cubic(int interp) { return interp != VT_LINEAR; }
+bool is_filtered(int interp) { return interp == VT_FILT_BSPLINE || interp == VT_FILT_BSPLINE_SIMPLE; }
+
+}  // namespace
+
+struct vt_volume {
+    int dev = 0;
+    int interp = 0;
+    int D = 0, H = 0, W = 0;           // resident source dims
+    int oD = 0, oH = 0, oW = 0;        // output dims
+    int64_t plane0 = 0;                // global index of resident plane 0
+    int64_t gD = 0;                    // global depth
+    int64_t out_plane0 = 0;            // global index of output plane 0
+    float* d_src = nullptr;
+    float* d_scratch_out = nullptr;    // staging for host outputs
+    size_t scratch_elems = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float prefilter_ms = 0.f;
+    int lds_limit = 160 * 1024;
+    int cu_count = 256;
+    // last launch, for vt_volume_info
+    int last_kernel = 0, last_tile[3] = {0, 0, 0}, last_lds[3] = {0, 0, 0}, last_lds_bytes = 0, last_grid = 0;
+    int force_cfg = -1;                // VT_TILE environment override (experiments)
+};
+
+namespace {
+
+// Run the three passes X, Y, Z (reference order, transforms.py:305-307) on d_a, using d_b as the
+// ping-pong partner.  Returns which buffer holds the coefficients.
+int run_prefilter(float* d_a, float* d_b, int D, int H, int W, bool lo_interior_axis0, hipStream_t st, float** result)
+{
+    float* cur = d_a;
+    float* oth = d_b;
+    const int order[3] = {2, 1, 0};
+    for (int i = 0; i < 3; ++i) {
+        const int axis = order[i];
+        const bool interior = (axis == 0) && lo_interior_axis0;
+        if (prefilter_axis_in_place_ok(axis, D, H, W)) {
+            VT_HIP(launch_prefilter_axis(axis, cur, cur, D, H, W, interior, st));
+        } else {
+            VT_HIP(launch_prefilter_axis(axis, cur, oth, D, H, W, interior, st));
+            float* t = cur; cur = oth; oth = t;
+        }
+    }
+    *result = cur;
+    return 0;
+}
+
+// Choose the kernel and tile shape for one matrix (host side, a few hundred flops).
+int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, TilePlan* plan)
+{
+    const bool cubic = is_cubic(v->interp);
+    const int64_t n_out = (int64_t)v->oD * v->oH * v->oW;
+    const bool vec4 = (v->W % 4 == 0) && ((reinterpret_cast<uintptr_t>(v->d_src) & 15) == 0);
+
+    std::memcpy(p->m, m, sizeof(double) * 12);
+    p->sD = v->D; p->sH = v->H; p->sW = v->W;
+    p->oD = v->oD; p->oH = v->oH; p->oW = v->oW;
+    p->flags = flags & VT_KEEP_OUTSIDE;
+    // skirt rule src + 0.5 in [0, dim) on the global volume, expressed on resident coordinates
+    p->vlo[0] = -0.5 - (double)v->plane0;  p->vhi[0] = (double)v->gD - 0.5 - (double)v->plane0;
+    p->vlo[1] = -0.5;                      p->vhi[1] = (double)v->H - 0.5;
+    p->vlo[2] = -0.5;                      p->vhi[2] = (double)v->W - 0.5;
+
+    plan->kind = 1; plan->cfg = -1; plan->td = plan->th = plan->tw = 0; plan->lds_bytes = 0; plan->grid = 0; plan->vec4 = vec4;
+    bool want_tiled = n_out >= 64 * 64 * 64;
+    if (flags & VT_FORCE_TILED) want_tiled = true;
+    if (flags & VT_FORCE_DIRECT) want_tiled = false;
+    for (int i = 0; i < 12; ++i)
+        if (!std::isfinite(m[i])) return fail(VT_EINVAL, "matrix entry %d is not finite", i);
+    if (!want_tiled) return 0;
+
+    const int halo2 = cubic ? 2 : 0;           // cubic taps reach one voxel further on each side
+    double best_cost = 1e300;
+    for (int c = 0; c < tile_config_count(); ++c) {
+        if (v->force_cfg >= 0 && c != v->force_cfg) continue;
+        int T[3];
+        tile_config(c, &T[0], &T[1], &T[2]);
+        int L[3];
+        bool ok = true;
+        for (int r = 0; r < 3 && ok; ++r) {
+            double ext = 0;
+            for (int k = 0; k < 3; ++k) ext += std::fabs(m[4 * r + k]) * (T[k] - 1);
+            if (!(ext < 4096.0)) { ok = false; break; }
+            L[r] = (int)std::floor(ext) + 3 + halo2;       // floor(hi)-floor(lo) <= floor(ext)+1, +1 upper tap, +1 slack
+        }
+        if (!ok) continue;
+        if (vec4) L[2] = (L[2] + 3 + 3) & ~3;              // origin aligned down by up to 3, stride multiple of 4
+        const int64_t bytes = (int64_t)L[0] * L[1] * L[2] * 4;
+        if (bytes > v->lds_limit) continue;
+        const int blocks_per_cu = (int)std::min<int64_t>(8, (160 * 1024) / bytes);
+        const double vox = (double)T[0] * T[1] * T[2];
+        // staged bytes per output voxel, penalised when fewer than 3 workgroups fit a CU (no overlap of
+        // one workgroup's staging with another's gather)
+        double cost = (double)bytes / vox * (blocks_per_cu >= 3 ? 1.0 : (blocks_per_cu == 2 ? 1.25 : 2.0));
+        if (cost < best_cost) {
+            best_cost = cost;
+            plan->kind = 2; plan->cfg = c; plan->td = T[0]; plan->th = T[1]; plan->tw = T[2];
+            plan->lds_bytes = (int)bytes;
+            p->Lz = L[0]; p->Ly = L[1]; p->Lx = L[2];
+        }
+    }
+    if (plan->kind != 2) return 0;             // footprint does not fit LDS: direct gather
+
+    const int T[3] = {plan->td, plan->th, plan->tw};
+    for (int r = 0; r < 3; ++r) {
+        double neg = 0, pos = 0;
+        for (int k = 0; k < 3; ++k) {
+            const double e = m[4 * r + k] * (T[k] - 1);
+            if (e < 0) neg += e; else pos += e;
+        }
+        p->neg[r] = neg; p->pos[r] = pos;
+    }
+    p->nTd = (v->oD + T[0] - 1) / T[0];
+    p->nTh = (v->oH + T[1] - 1) / T[1];
+    p->nTw = (v->oW + T[2] - 1) / T[2];
+    const int64_t grid = (int64_t)p->nTd * p->nTh * p->nTw;
+    if (grid > 0x7fffffffLL) { plan->kind = 1; return 0; }
+    plan->grid = (int)grid;
+    return 0;
+}
+
+int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
+{
+    if (!v || !m4x4 || !out) return fail(VT_EINVAL, "NULL argument");
+    int rc = use_device(v->dev);
+    if (rc) return rc;
+
+    // fold the output-plane offset and the resident-window offset into the translation column:
+    // src_resident = M . (d + out_plane0, h, w, 1) - (plane0, 0, 0)
+    double m[12];
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 4; ++c) m[4 * r + c] = m4x4[4 * r + c];
+        m[4 * r + 3] = std::fma(m4x4[4 * r], (double)v->out_plane0, m4x4[4 * r + 3]);
+    }
+    m[3] -= (double)v->plane0;
+
+    AffineParams p;
+    std::memset(&p, 0, sizeof(p));
+    TilePlan plan;
+    rc = plan_launch(v, m, flags, &p, &plan);
+    if (rc) return rc;
+
+    const size_t n_out = (size_t)v->oD * v->oH * v->oW;
+    float* d_out = out;
+    const bool host_out = !(flags & VT_OUT_DEVICE);
+    if (host_out) {
+        if (v->scratch_elems < n_out) {
+            if (v->d_scratch_out) { VT_HIP(hipFree(v->d_scratch_out)); v->d_scratch_out = nullptr; v->scratch_elems = 0; }
+            VT_HIP(hipMalloc(reinterpret_cast<void**>(&v->d_scratch_out), n_out * sizeof(float)));
+            v->scratch_elems = n_out;
+        }
+        d_out = v->d_scratch_out;
+        if (flags & VT_KEEP_OUTSIDE)   // caller's stale values must survive: bring them in first
+            VT_HIP(hipMemcpyAsync(d_out, out, n_out * sizeof(float), hipMemcpyHostToDevice, v->stream));
+    }
+
+    if (plan.kind == 2) {
+        VT_HIP(launch_affine_tiled(plan.cfg, v->interp, plan.vec4, v->d_src, d_out, p, plan.grid, plan.lds_bytes, v->stream));
+        v->last_kernel = 2;
+        v->last_tile[0] = plan.td; v->last_tile[1] = plan.th; v->last_tile[2] = plan.tw;
+        v->last_lds[0] = p.Lz; v->last_lds[1] = p.Ly; v->last_lds[2] = p.Lx;
+        v->last_lds_bytes = plan.lds_bytes; v->last_grid = plan.grid;
+    } else {
+        VT_HIP(launch_affine_direct(v->interp, v->d_src, d_out, p, v->stream));
+        v->last_kernel = 1;
+        v->last_tile[0] = v->last_tile[1] = v->last_tile[2] = 0;
+        v->last_lds[0] = v->last_lds[1] = v->last_lds[2] = 0;
+        v->last_lds_bytes = 0; v->last_grid = (int)((n_out + 255) / 256);
+    }
+
+    if (host_out) {
+        VT_HIP(hipMemcpyAsync(out, d_out, n_out * sizeof(float), hipMemcpyDeviceToHost, v->stream));
+        VT_HIP(hipStreamSynchronize(v->stream));
+    }
+    return 0;
+}
+
+int create_common(int dev, int D, int H, int W, int interp, const float* data, int cflags,
+                  int64_t plane0, int64_t gD, int64_t out_plane0, int oD, vt_volume_t** out)
+{
+    if (!out) return fail(VT_EINVAL, "NULL handle pointer");
+    *out = nullptr;
+    if (!data) return fail(VT_EINVAL, "NULL data pointer");
+    if (D <= 0 || H <= 0 || W <= 0 || oD <= 0) return fail(VT_EINVAL, "non-positive dims (%d,%d,%d) out depth %d", D, H, W, oD);
+    if (interp < VT_LINEAR || interp > VT_FILT_BSPLINE_SIMPLE) return fail(VT_EINVAL, "unknown interpolation code %d", interp);
+    if ((int64_t)D * H > 0x7fffffffLL || (int64_t)H * W > 0x7fffffffLL) return fail(VT_EUNSUPPORTED, "plane count/size exceeds 2^31");
+    if (gD <= 0 || plane0 + D < 0 || plane0 > gD) return fail(VT_EINVAL, "slab window [%lld,%lld) outside global depth %lld",
+                                                               (long long)plane0, (long long)(plane0 + D), (long long)gD);
+    int rc = init_device(dev);
+    if (rc) return rc;
+
+    vt_volume* v = new (std::nothrow) vt_volume();
+    if (!v) return fail(VT_ENOMEM, "out of host memory");
+    v->dev = dev; v->interp = interp; v->D = D; v->H = H; v->W = W;
+    v->oD = oD; v->oH = H; v->oW = W;
+    v->plane0 = plane0; v->gD = gD; v->out_plane0 = out_plane0;
+    if (const char* t = std::getenv("VT_TILE")) v->force_cfg = std::atoi(t);
+
+    auto cleanup = [&](int code) {
+        vt_volume_destroy(v);
+        return code;
+    };
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) return cleanup(fail((int)e, "hipGetDeviceProperties: %s", hipGetErrorString(e)));
+    v->cu_count = prop.multiProcessorCount;
+    v->lds_limit = (int)std::min<size_t>(160 * 1024, prop.sharedMemPerBlock > 0 ? prop.sharedMemPerBlock : 65536);
+
+#define VT_HIPC(call)                                                                                     \
+    do {                                                                                                  \
+        hipError_t e_ = (call);                                                                           \
+        if (e_ != hipSuccess)                                                                             \
+            return cleanup(fail((int)e_, "%s: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__)); \
+    } while (0)
+
+    // a blocking stream: ordered against the legacy null stream (torch's default), like the reference,
+    // which does everything on cupy's null stream (transforms.py:168, volume.py:66)
+    VT_HIPC(hipStreamCreateWithFlags(&v->stream, hipStreamDefault));
+    VT_HIPC(hipEventCreate(&v->ev0));
+    VT_HIPC(hipEventCreate(&v->ev1));
+    const size_t bytes = (size_t)D * H * W * sizeof(float);
+    VT_HIPC(hipMalloc(reinterpret_cast<void**>(&v->d_src), bytes));
+    VT_HIPC(hipMemcpyAsync(v->d_src, data, bytes, (cflags & VT_SRC_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, v->stream));
+
+    if (is_filtered(interp)) {
+        float* d_tmp = nullptr;
+        VT_HIPC(hipMalloc(reinterpret_cast<void**>(&d_tmp), bytes));
+        float* res = nullptr;
+        hipEventRecord(v->ev0, v->stream);
+        rc = run_prefilter(v->d_src, d_tmp, D, H, W, (cflags & VT_SLAB_LO_INTERIOR) != 0, v->stream, &res);
+        hipEventRecord(v->ev1, v->stream);
+        hipError_t es = hipStreamSynchronize(v->stream);
+        if (rc || es != hipSuccess) {
+            hipFree(d_tmp);
+            if (!rc) rc = fail((int)es, "prefilter: %s", hipGetErrorString(es));
+            return cleanup(rc);
+        }
+        hipEventElapsedTime(&v->prefilter_ms, v->ev0, v->ev1);
+        if (res == d_tmp) { hipFree(v->d_src); v->d_src = d_tmp; }
+        else hipFree(d_tmp);
+    } else {
+        VT_HIPC(hipStreamSynchronize(v->stream));
+    }
+#undef VT_HIPC
+    *out = v;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* vt_last_error(void) { return g_err; }
+const char* vt_version(void) { return "voltools_amd 0.1.0 (gfx950)"; }
+
+int vt_device_count(int* count)
+{
+    if (!count) return fail(VT_EINVAL, "NULL count");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    *count = (e == hipSuccess && n > 0) ? n : 0;     // "no device" is an answer, not an error
+    return 0;
+}
+
+int vt_device_name(int dev, char* buf, int buflen)
+{
+    if (!buf || buflen <= 0) return fail(VT_EINVAL, "bad buffer");
+    int rc = use_device(dev);
+    if (rc) return rc;
+    hipDeviceProp_t prop;
+    VT_HIP(hipGetDeviceProperties(&prop, dev));
+    snprintf(buf, (size_t)buflen, "%s (%s)", prop.name, prop.gcnArchName);
+    return 0;
+}
+
+int vt_device_props(int dev, int* cu_count, int* lds_bytes_per_block, uint64_t* hbm_bytes)
+{
+    int rc = use_device(dev);
+    if (rc) return rc;
+    hipDeviceProp_t prop;
+    VT_HIP(hipGetDeviceProperties(&prop, dev));
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (lds_bytes_per_block) *lds_bytes_per_block = (int)prop.sharedMemPerBlock;
+    if (hbm_bytes) *hbm_bytes = (uint64_t)prop.totalGlobalMem;
+    return 0;
+}
+
+int vt_device_synchronize(int dev)
+{
+    int rc = use_device(dev);
+    if (rc) return rc;
+    VT_HIP(hipDeviceSynchronize());
+    return 0;
+}
+
+int vt_malloc(int dev, size_t bytes, void** dptr)
+{
+    if (!dptr || bytes == 0) return fail(VT_EINVAL, "bad arguments");
+    int rc = use_device(dev);
+    if (rc) return rc;
+    VT_HIP(hipMalloc(dptr, bytes));
+    return 0;
+}
+
+int vt_free(int dev, void* dptr)
+{
+    if (!dptr) return 0;
+    int rc = use_device(dev);
+    if (rc) return rc;
+    VT_HIP(hipFree(dptr));
+    return 0;
+}
+
+int vt_memset_zero(int dev, void* dptr, size_t bytes)
+{
+    if (!dptr) return fail(VT_EINVAL, "NULL pointer");
+    int rc = use_device(dev);
+    if (rc) return rc;
+    VT_HIP(hipMemset(dptr, 0, bytes));
+    return 0;
+}
+
+int vt_memcpy_h2d(int dev, void* dptr, const void* hptr, size_t bytes)
+{
+    if (!dptr || !hptr) return fail(VT_EINVAL, "NULL pointer");
+    int rc = use_device(dev);
+    if (rc) return rc;
+    VT_HIP(hipMemcpy(dptr, hptr, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int vt_memcpy_d2h(int dev, void* hptr, const void* dptr, size_t bytes)
+{
+    if (!dptr || !hptr) return fail(VT_EINVAL, "NULL pointer");
+    int rc = use_device(dev);
+    if (rc) return rc;
+    VT_HIP(hipMemcpy(hptr, dptr, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int vt_memcpy_d2d(int dev, void* dst, const void* src, size_t bytes)
+{
+    if (!dst || !src) return fail(VT_EINVAL, "NULL pointer");
+    int rc = use_device(dev);
+    if (rc) return rc;
+    VT_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice));
+    return 0;
+}
+
+int vt_volume_create(int dev, int depth, int height, int width, int interp, const float* data,
+                     int create_flags, vt_volume_t** out)
+{
+    return create_common(dev, depth, height, width, interp, data, create_flags & VT_SRC_DEVICE,
+                         0, depth, 0, depth, out);
+}
+
+int vt_volume_create_slab(int dev, int local_depth, int height, int width, int interp, const float* data,
+                          int create_flags, int64_t plane0, int64_t global_depth, int64_t out_plane0,
+                          int out_depth, vt_volume_t** out)
+{
+    return create_common(dev, local_depth, height, width, interp, data, create_flags,
+                         plane0, global_depth, out_plane0, out_depth, out);
+}
+
+int vt_volume_destroy(vt_volume_t* v)
+{
+    if (!v) return 0;
+    hipSetDevice(v->dev);
+    if (v->stream) hipStreamSynchronize(v->stream);
+    if (v->d_src) hipFree(v->d_src);
+    if (v->d_scratch_out) hipFree(v->d_scratch_out);
+    if (v->ev0) hipEventDestroy(v->ev0);
+    if (v->ev1) hipEventDestroy(v->ev1);
+    if (v->stream) hipStreamDestroy(v->stream);
+    delete v;
+    return 0;
+}
+
+int vt_volume_info(const vt_volume_t* v, vt_volume_info_t* info)
+{
+    if (!v || !info) return fail(VT_EINVAL, "NULL argument");
+    info->device = v->dev; info->interp = v->interp;
+    info->depth = v->D; info->height = v->H; info->width = v->W;
+    info->out_depth = v->oD; info->out_height = v->oH; info->out_width = v->oW;
+    info->last_kernel = v->last_kernel;
+    for (int i = 0; i < 3; ++i) { info->last_tile[i] = v->last_tile[i]; info->last_lds_dims[i] = v->last_lds[i]; }
+    info->last_lds_bytes = v->last_lds_bytes; info->last_grid = v->last_grid;
+    info->prefilter_ms = v->prefilter_ms;
+    info->resident_bytes = (uint64_t)v->D * v->H * v->W * sizeof(float);
+    return 0;
+}
+
+int vt_volume_stream(const vt_volume_t* v, void** hip_stream)
+{
+    if (!v || !hip_stream) return fail(VT_EINVAL, "NULL argument");
+    *hip_stream = reinterpret_cast<void*>(v->stream);
+    return 0;
+}
+
+int vt_volume_sync(vt_volume_t* v)
+{
+    if (!v) return fail(VT_EINVAL, "NULL handle");
+    int rc = use_device(v->dev);
+    if (rc) return rc;
+    VT_HIP(hipStreamSynchronize(v->stream));
+    return 0;
+}
+
+int vt_volume_set_output_shape(vt_volume_t* v, int od, int oh, int ow)
+{
+    if (!v) return fail(VT_EINVAL, "NULL handle");
+    if (od <= 0 || oh <= 0 || ow <= 0) return fail(VT_EINVAL, "non-positive output dims");
+    if ((int64_t)od * oh > 0x7fffffffLL || (int64_t)oh * ow > 0x7fffffffLL) return fail(VT_EUNSUPPORTED, "output too large");
+    v->oD = od; v->oH = oh; v->oW = ow;
+    return 0;
+}
+
+int vt_volume_affine(vt_volume_t* v, const float* m4x4, float* out, int flags)
+{
+    if (!m4x4) return fail(VT_EINVAL, "NULL matrix");
+    double m[16];
+    for (int i = 0; i < 16; ++i) m[i] = (double)m4x4[i];
+    return do_affine(v, m, out, flags);
+}
+
+int vt_volume_affine_f64(vt_volume_t* v, const double* m4x4, float* out, int flags)
+{
+    return do_affine(v, m4x4, out, flags);
+}
+
+int vt_timer_start(vt_volume_t* v)
+{
+    if (!v) return fail(VT_EINVAL, "NULL handle");
+    int rc = use_device(v->dev);
+    if (rc) return rc;
+    VT_HIP(hipEventRecord(v->ev0, v->stream));
+    return 0;
+}
+
+int vt_timer_stop(vt_volume_t* v, float* ms)
+{
+    if (!v || !ms) return fail(VT_EINVAL, "NULL argument");
+    int rc = use_device(v->dev);
+    if (rc) return rc;
+    VT_HIP(hipEventRecord(v->ev1, v->stream));
+    VT_HIP(hipEventSynchronize(v->ev1));
+    VT_HIP(hipEventElapsedTime(ms, v->ev0, v->ev1));
+    return 0;
+}
+
+int vt_prefilter_inplace(int dev, float* d_volume, int D, int H, int W)
+{
+    if (!d_volume) return fail(VT_EINVAL, "NULL volume");
+    if (D <= 0 || H <= 0 || W <= 0) return fail(VT_EINVAL, "non-positive dims");
+    if ((int64_t)D * H > 0x7fffffffLL || (int64_t)H * W > 0x7fffffffLL) return fail(VT_EUNSUPPORTED, "volume too large");
+    int rc = init_device(dev);
+    if (rc) return rc;
+    const size_t bytes = (size_t)D * H * W * sizeof(float);
+    float* d_tmp = nullptr;
+    VT_HIP(hipMalloc(reinterpret_cast<void**>(&d_tmp), bytes));
+    float* res = nullptr;
+    rc = run_prefilter(d_volume, d_tmp, D, H, W, false, nullptr, &res);
+    if (!rc && res != d_volume) {
+        hipError_t e = hipMemcpyAsync(d_volume, res, bytes, hipMemcpyDeviceToDevice, nullptr);
+        if (e != hipSuccess) rc = fail((int)e, "copy back: %s", hipGetErrorString(e));
+    }
+    hipError_t es = hipStreamSynchronize(nullptr);
+    hipFree(d_tmp);
+    if (!rc && es != hipSuccess) rc = fail((int)es, "prefilter: %s", hipGetErrorString(es));
+    return rc;
+}
+
+int vt_affine_oneshot(int dev, const float* h_volume, int D, int H, int W, int interp, const float* m4x4,
+                      float* h_out, int flags, float* elapsed_ms)
+{
+    if (!h_volume || !m4x4 || !h_out) return fail(VT_EINVAL, "NULL argument");
+    int rc = init_device(dev);
+    if (rc) return rc;
+    hipEvent_t t0, t1;
+    VT_HIP(hipEventCreate(&t0));
+    VT_HIP(hipEventCreate(&t1));
+    hipEventRecord(t0, nullptr);
+    vt_volume_t* v = nullptr;
+    rc = vt_volume_create(dev, D, H, W, interp, h_volume, 0, &v);
+    if (!rc) rc = vt_volume_affine(v, m4x4, h_out, flags & ~VT_OUT_DEVICE);
+    hipEventRecord(t1, nullptr);
+    hipEventSynchronize(t1);
+    if (elapsed_ms) hipEventElapsedTime(elapsed_ms, t0, t1);
+    hipEventDestroy(t0);
+    hipEventDestroy(t1);
+    vt_volume_destroy(v);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,54 @@
+// vt_internal.h -- shared declarations of the HIP library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/voltools_hip.h"
+
+namespace vt {
+
+// Prefilter constants in float32, evaluated the way the reference's device code does
+// (helper_math.h:1468 `Pole = sqrt(3.0f)-2.0f`; bspline.h:36 Lambda; bspline.h:27 anticausal gain).
+constexpr float kPole   = -0x1.126148p-2f;   // -0.26794922
+constexpr float kLambda =  0x1.7ffffep+2f;   //  5.9999995 = (1-Pole)*(1-1/Pole)
+constexpr float kAntiInit = 0x1.b0cb1ap-3f;  //  0.21132489 = Pole/(Pole-1)
+
+// Kernel argument block of the transform kernels.  Lives in the kernarg segment, i.e. it is read with
+// scalar loads into SGPRs once per wave ("matrix broadcast from constant memory").
+struct AffineParams {
+    double m[12];      // 3x4 pull matrix in array-axis order; output-plane and slab offsets folded into m[r][3]
+    double neg[3];     // sum_c min(0, m[r][c]*(T_c-1)): lowest source coordinate of a tile relative to its base
+    double pos[3];     // sum_c max(0, m[r][c]*(T_c-1))
+    double vlo[3];     // valid source interval [vlo, vhi) per axis: the skirt rule src+0.5 in [0, dim)
+    double vhi[3];
+    int32_t sD, sH, sW;        // resident source dims (storage)
+    int32_t oD, oH, oW;        // output dims
+    int32_t nTd, nTh, nTw;     // output tile counts
+    int32_t Lz, Ly, Lx;        // staged source box (floats); Lx is the LDS row stride
+    int32_t flags;             // VT_KEEP_OUTSIDE
+};
+
+struct TilePlan {
+    int kind;            // 1 direct, 2 tiled
+    int cfg;             // index into the tile table
+    int td, th, tw;
+    int lds_bytes;
+    int grid;
+    bool vec4;
+};
+
+// launchers (vt_kernels_affine.hip)
+int tile_config_count();
+void tile_config(int idx, int* td, int* th, int* tw);
+hipError_t launch_affine_tiled(int cfg, int interp, bool vec4, const float* src, float* out,
+                               const AffineParams& p, int grid, int lds_bytes, hipStream_t stream);
+hipError_t launch_affine_direct(int interp, const float* src, float* out, const AffineParams& p,
+                                hipStream_t stream);
+hipError_t init_affine_kernels();   // raises the dynamic-LDS limit of every tiled instantiation
+
+// prefilter (vt_kernels_prefilter.hip).  src -> dst; `*in_place_ok` tells whether src == dst is legal.
+// axis: 0 (Z, stride H*W), 1 (Y, stride W), 2 (X, contiguous).
+hipError_t launch_prefilter_axis(int axis, const float* src, float* dst, int D, int H, int W,
+                                 bool lo_interior, hipStream_t stream);
+bool prefilter_axis_in_place_ok(int axis, int D, int H, int W);
+
+}  // namespace vt

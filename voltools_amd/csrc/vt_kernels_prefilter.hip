@@ -1,0 +1,254 @@
+// vt_kernels_prefilter.hip -- the separable cubic B-spline prefilter as three 1-D recursive passes.
+//
+// Reference: ConvertToInterpolationCoefficients (bspline.h:30-54) applied along X, Y, Z by
+// SamplesToCoefficients3DX/Y/Z (bspline.h:58-99), one *thread per line*, each thread sweeping its line
+// twice in global memory (causal, then anticausal).  On 512^3 that is 262144 threads with 2x512
+// dependent steps each, an uncoalesced X pass, and every sample read and written twice per pass.
+//
+// Here the same recursion
+//     c+[0] = L*(s[0] + sum_{n<min(12,N)} z^(n+1) s[n]);  c+[n] = L*s[n] + z*c+[n-1]
+//     c[N-1] = z/(z-1) * c+[N-1];                         c[n]  = z*(c[n+1] - c+[n])
+// (z = sqrt(3)-2, L = (1-z)(1-1/z)) is organised for a 64-wide wavefront machine:
+//
+//   X pass (contiguous lines): one wavefront per line, 64 consecutive samples per step held one per lane.
+//     The first-order recursion is evaluated as a wave-level scan (log-step Hillis-Steele with the
+//     ratio z^s, data moved with ds_bpermute via __shfl_up/__shfl_down), the carry between 64-sample
+//     segments is a single readlane.  Loads and stores are fully coalesced, the whole line stays in
+//     registers between the causal and the anticausal sweep: 4 B read + 4 B written per sample.
+//
+//   Y / Z passes (strided lines): lanes run along x (coalesced), and every lane owns a *chunk* of C
+//     samples of one line.  Because |z|^16 = 7e-10, a chunk only needs K = 16 samples of warm-up before
+//     it (causal) and after it (anticausal) to reproduce the full-line recursion to float32 precision;
+//     the first and last chunk of a line use the reference's exact initialisations.  The chunk lives in
+//     registers between the two sweeps, so HBM sees one read (plus warm-up overlap, absorbed by L2) and
+//     one write per sample, and a 512^3 pass exposes 2M independent lanes instead of 262144.
+//     Chunked passes read neighbours' samples, so they run out of place (ping-pong buffers).
+#include "vt_internal.h"
+
+namespace vt {
+
+__device__ __forceinline__ float zpow_small(int e)   // kPole^e for 0 <= e <= 127 by binary decomposition
+{
+    constexpr float z1 = kPole, z2 = z1 * z1, z4 = z2 * z2, z8 = z4 * z4, z16 = z8 * z8, z32 = z16 * z16, z64 = z32 * z32;
+    float r = 1.0f;
+    r *= (e & 1) ? z1 : 1.0f;
+    r *= (e & 2) ? z2 : 1.0f;
+    r *= (e & 4) ? z4 : 1.0f;
+    r *= (e & 8) ? z8 : 1.0f;
+    r *= (e & 16) ? z16 : 1.0f;
+    r *= (e & 32) ? z32 : 1.0f;
+    r *= (e & 64) ? z64 : 1.0f;
+    return r;
+}
+
+// inclusive scan y[l] = t[l] + z*y[l-1] over the 64 lanes of a wave (y[-1] = 0)
+__device__ __forceinline__ float wave_scan_up(float t, int lane)
+{
+    constexpr float z1 = kPole, z2 = z1 * z1, z4 = z2 * z2, z8 = z4 * z4, z16 = z8 * z8, z32 = z16 * z16;
+    float u;
+    u = __shfl_up(t, 1);  t = (lane >= 1)  ? fmaf(z1, u, t)  : t;
+    u = __shfl_up(t, 2);  t = (lane >= 2)  ? fmaf(z2, u, t)  : t;
+    u = __shfl_up(t, 4);  t = (lane >= 4)  ? fmaf(z4, u, t)  : t;
+    u = __shfl_up(t, 8);  t = (lane >= 8)  ? fmaf(z8, u, t)  : t;
+    u = __shfl_up(t, 16); t = (lane >= 16) ? fmaf(z16, u, t) : t;
+    u = __shfl_up(t, 32); t = (lane >= 32) ? fmaf(z32, u, t) : t;
+    return t;
+}
+
+// inclusive reverse scan y[l] = t[l] + z*y[l+1] (y[64] = 0)
+__device__ __forceinline__ float wave_scan_down(float t, int lane)
+{
+    constexpr float z1 = kPole, z2 = z1 * z1, z4 = z2 * z2, z8 = z4 * z4, z16 = z8 * z8, z32 = z16 * z16;
+    float u;
+    u = __shfl_down(t, 1);  t = (lane < 63) ? fmaf(z1, u, t)  : t;
+    u = __shfl_down(t, 2);  t = (lane < 62) ? fmaf(z2, u, t)  : t;
+    u = __shfl_down(t, 4);  t = (lane < 60) ? fmaf(z4, u, t)  : t;
+    u = __shfl_down(t, 8);  t = (lane < 56) ? fmaf(z8, u, t)  : t;
+    u = __shfl_down(t, 16); t = (lane < 48) ? fmaf(z16, u, t) : t;
+    u = __shfl_down(t, 32); t = (lane < 32) ? fmaf(z32, u, t) : t;
+    return t;
+}
+
+__device__ __forceinline__ float wave_sum(float t)
+{
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) t += __shfl_xor(t, s);
+    return t;
+}
+
+// ---- X pass: one wave per contiguous line, NSEG segments of 64 samples in registers ----
+template <int NSEG>
+__global__ __launch_bounds__(256) void prefilter_x_scan(const float* __restrict__ src, float* __restrict__ dst,
+                                                         int W, int64_t nlines, int lo_interior)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t line = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (line >= nlines) return;                       // wave-uniform
+    const float* s = src + line * W;
+    float* o = dst + line * W;
+
+    float v[NSEG];
+#pragma unroll
+    for (int g = 0; g < NSEG; ++g) {
+        const int x = g * 64 + lane;
+        v[g] = (x < W) ? s[x] : 0.0f;
+    }
+
+    const float zl1 = zpow_small(lane + 1);           // z^(lane+1): weight of the incoming carry
+    // causal initialisation (bspline.h:2-19): s[0] + sum_{n < min(12,N)} z^(n+1) s[n]
+    float init;
+    {
+        const int horizon = W < 12 ? W : 12;
+        const float term = (lane < horizon) ? zl1 * v[0] : 0.0f;
+        init = __shfl(v[0], 0) + wave_sum(term);
+        if (lo_interior) init = __shfl(v[0], 0) * (1.0f / (1.0f - kPole));   // steady-state guess
+    }
+    float carry = 0.0f;
+#pragma unroll
+    for (int g = 0; g < NSEG; ++g) {
+        float t = kLambda * v[g];
+        if (g == 0) t = (lane == 0) ? kLambda * init : t;
+        t = wave_scan_up(t, lane);
+        t = fmaf(zl1, carry, t);
+        carry = __shfl(t, 63);
+        v[g] = t;                                     // c+
+    }
+
+    // anticausal: c[n] = u[n] + z*c[n+1], u[N-1] = z/(z-1)*c+[N-1], u[n<N-1] = -z*c+[n], u[n>=N] = 0
+    const float zr = zpow_small(64 - lane);           // z^(64-lane): weight of the carry from the next segment
+    carry = 0.0f;
+#pragma unroll
+    for (int g = NSEG - 1; g >= 0; --g) {
+        const int x = g * 64 + lane;
+        float u = (x < W - 1) ? (-kPole) * v[g] : ((x == W - 1) ? kAntiInit * v[g] : 0.0f);
+        u = wave_scan_down(u, lane);
+        u = fmaf(zr, carry, u);
+        carry = __shfl(u, 0);
+        if (x < W) o[x] = u;
+    }
+}
+
+// ---- strided passes: one lane per (line, chunk), chunk + warm-up in registers ----
+template <int C, int K>
+__global__ __launch_bounds__(256) void prefilter_chunked(const float* __restrict__ src, float* __restrict__ dst,
+                                                          int N, int64_t es,          // line length, element stride
+                                                          int nA, int64_t sA,         // lane axis (coalesced)
+                                                          int nB, int64_t sB,         // outer axis
+                                                          int nchunks, int lo_interior)
+{
+    static_assert(C >= K && K >= 12, "chunk geometry");
+    constexpr int R = C + 2 * K;
+    const int lane = threadIdx.x & 63;
+    const int nAb = (nA + 63) >> 6;
+    const int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int ab = (int)(gw % nAb);
+    const int64_t rest = gw / nAb;
+    const int bi = (int)(rest % nB);
+    const int chunk = (int)(rest / nB);
+    if (chunk >= nchunks) return;                     // wave-uniform
+
+    const int ai = ab * 64 + lane;
+    const bool active = ai < nA;
+    const int64_t lane_off = (int64_t)bi * sB + (int64_t)(active ? ai : nA - 1) * sA;
+    const float* s = src + lane_off;
+    float* o = dst + lane_off;
+
+    const int a = chunk * C;                          // chunk covers [a, b)
+    const int b = min(a + C, N);
+    const int e = min(b + K, N);                      // anticausal sweep starts at e-1
+    const int kl = e - 1 - a + K;                     // register index of position e-1
+
+    float v[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        int pos = a - K + k;
+        pos = max(0, min(pos, N - 1));
+        v[k] = s[(int64_t)pos * es];
+    }
+
+    // causal sweep
+    float y;
+    if (a == 0) {
+        // positions < 0 do not exist: start at register K (position 0)
+        if (!lo_interior) {
+            float sum = v[K];
+            float zn = kPole;
+#pragma unroll
+            for (int n = 0; n < 12; ++n) {
+                if (n < N) sum += zn * v[K + n];
+                zn *= kPole;
+            }
+            y = kLambda * sum;
+        } else {
+            y = kLambda * v[K] * (1.0f / (1.0f - kPole));
+        }
+        v[K] = y;
+#pragma unroll
+        for (int k = K + 1; k < R; ++k) { y = fmaf(kPole, y, kLambda * v[k]); v[k] = y; }
+    } else {
+        y = kLambda * v[0] * (1.0f / (1.0f - kPole));   // steady state of a constant signal; forgotten after K steps
+        v[0] = y;
+#pragma unroll
+        for (int k = 1; k < R; ++k) { y = fmaf(kPole, y, kLambda * v[k]); v[k] = y; }
+    }
+
+    // anticausal sweep: the first valid position from the top uses c = z/(z-1)*c+ (exact at the line end,
+    // bspline.h:27; the steady-state guess inside a line)
+    float c = 0.0f;
+#pragma unroll
+    for (int k = R - 1; k >= K; --k) {
+        c = (k == kl) ? kAntiInit * v[k] : kPole * (c - v[k]);
+        v[k] = c;
+    }
+
+    if (active) {
+        const int cnt = b - a;
+#pragma unroll
+        for (int k = 0; k < C; ++k)
+            if (k < cnt) o[(int64_t)(a + k) * es] = v[K + k];
+    }
+}
+
+constexpr int kChunk = 64, kWarm = 16;
+
+bool prefilter_axis_in_place_ok(int axis, int D, int H, int W)
+{
+    if (axis == 2) return W <= 2048;                  // whole line in registers before any store
+    const int N = axis == 0 ? D : H;
+    return N <= kChunk;                               // single chunk: a lane reads its whole line first
+}
+
+hipError_t launch_prefilter_axis(int axis, const float* src, float* dst, int D, int H, int W,
+                                 bool lo_interior, hipStream_t stream)
+{
+    const int64_t plane = (int64_t)H * W;
+    if (axis == 2 && W <= 2048) {
+        const int64_t nlines = (int64_t)D * H;
+        const int64_t blocks = (nlines + 3) / 4;
+        if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+        const int nseg = (W + 63) / 64;
+        const dim3 g((unsigned)blocks), b(256);
+        const int li = lo_interior ? 1 : 0;
+        if (nseg <= 1) hipLaunchKernelGGL(prefilter_x_scan<1>, g, b, 0, stream, src, dst, W, nlines, li);
+        else if (nseg <= 2) hipLaunchKernelGGL(prefilter_x_scan<2>, g, b, 0, stream, src, dst, W, nlines, li);
+        else if (nseg <= 4) hipLaunchKernelGGL(prefilter_x_scan<4>, g, b, 0, stream, src, dst, W, nlines, li);
+        else if (nseg <= 8) hipLaunchKernelGGL(prefilter_x_scan<8>, g, b, 0, stream, src, dst, W, nlines, li);
+        else if (nseg <= 16) hipLaunchKernelGGL(prefilter_x_scan<16>, g, b, 0, stream, src, dst, W, nlines, li);
+        else hipLaunchKernelGGL(prefilter_x_scan<32>, g, b, 0, stream, src, dst, W, nlines, li);
+        return hipGetLastError();
+    }
+    int N, nA, nB;
+    int64_t es, sA, sB;
+    if (axis == 2) { N = W; es = 1; nA = H; sA = W; nB = D; sB = plane; }          // very wide lines: lanes along y
+    else if (axis == 1) { N = H; es = W; nA = W; sA = 1; nB = D; sB = plane; }
+    else { N = D; es = plane; nA = W; sA = 1; nB = H; sB = W; }
+    const int nchunks = (N + kChunk - 1) / kChunk;
+    const int64_t waves = (int64_t)((nA + 63) / 64) * nB * nchunks;
+    const int64_t blocks = (waves + 3) / 4;
+    if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((prefilter_chunked<kChunk, kWarm>), dim3((unsigned)blocks), dim3(256), 0, stream,
+                       src, dst, N, es, nA, sA, nB, sB, nchunks, lo_interior ? 1 : 0);
+    return hipGetLastError();
+}
+
+}  // namespace vt

@@ -1,0 +1,3 @@
+from .matrices import AVAILABLE_ROTATIONS, AVAILABLE_UNITS, translation_matrix, rotation_matrix, shear_matrix, \
+    scale_matrix, transform_matrix
+from .general import get_available_devices, switch_to_device, parse_device, compute_post_transform_dimensions
