@@ -66,10 +66,16 @@ def test_tiled_and_direct_match_oracle(interp, mname, shape):
     vol = rand_vol(shape, 1)
     m = MATRICES[mname](shape)
     want = oracle.affine(vol, m, interp)
-    for flags in (_native.FORCE_TILED, _native.FORCE_DIRECT):
+    kernels = set()
+    for flags in (_native.FORCE_TILED, _native.FORCE_TILED | _native.NO_ZSEP, _native.FORCE_DIRECT):
         got, info = run_case(vol, m, interp, flags)
+        kernels.add(info.last_kernel)
         err = np.abs(got - want).max()
         assert err <= TOL[interp], f'{interp}/{mname}/{shape} flags={flags} kernel={info.last_kernel} err={err}'
+    if mname in ('identity', 'shift_int', 'shift_frac', 'rot_inplane45'):
+        assert 3 in kernels          # the axis-0-separable kernel was exercised
+    if mname not in ('minify_big', 'far_outside'):
+        assert 2 in kernels and 1 in kernels
 
 
 @pytest.mark.parametrize('interp', ['linear', 'bspline', 'filt_bspline'])
@@ -79,6 +85,10 @@ def test_default_dispatch_uses_tiled_kernel_on_large_volumes(interp):
     m = MATRICES['rot_general'](shape)
     got, info = run_case(vol, m, interp)
     assert info.last_kernel == 2 and info.last_lds_bytes > 0
+    m = MATRICES['rot_inplane45'](shape)
+    got, info = run_case(vol, m, interp)
+    assert info.last_kernel == 3
+    assert np.abs(got - oracle.affine(vol, m, interp)).max() <= TOL[interp]
     assert np.abs(got - oracle.affine(vol, m, interp)).max() <= TOL[interp]
 
 
@@ -89,7 +99,7 @@ def test_degenerate_and_ragged_shapes(shape, interp):
     for mname in ('identity', 'shift_frac', 'rot_general'):
         m = MATRICES[mname](shape)
         want = oracle.affine(vol, m, interp)
-        for flags in (_native.FORCE_TILED, _native.FORCE_DIRECT):
+        for flags in (_native.FORCE_TILED, _native.FORCE_TILED | _native.NO_ZSEP, _native.FORCE_DIRECT):
             got, _ = run_case(vol, m, interp, flags)
             assert np.abs(got - want).max() <= TOL[interp], (shape, interp, mname, flags)
 
@@ -238,7 +248,7 @@ def test_full_size_properties_512(interp):
     # identity: linear returns the input bit-for-bit; filt_bspline reproduces it in the interior
     sv.affine(np.eye(4, dtype=np.float32), output=out)
     got = out.get()
-    assert sv.info().last_kernel == 2
+    assert sv.info().last_kernel == 3
     if interp == 'linear':
         assert np.array_equal(got, vol)
     else:
@@ -254,7 +264,7 @@ def test_full_size_properties_512(interp):
     m = vt.utils.transform_matrix(rotation=(0, 45, 0), center=centre((n, n, n)))
     sv.affine(m, output=out)
     got = out.get()
-    assert sv.info().last_kernel == 2
+    assert sv.info().last_kernel == 3
     d0 = 200
     src = vol if interp == 'linear' else None
     if interp == 'linear':
@@ -264,8 +274,19 @@ def test_full_size_properties_512(interp):
     m = vt.utils.transform_matrix(rotation=(25, -40, 70), rotation_order='sxyz', center=centre((n, n, n)))
     sv.affine(m, output=out)
     a = out.get()
+    assert sv.info().last_kernel == 2
     sv.affine(m, output=out, _flags=_native.FORCE_DIRECT)
     b = out.get()
     assert np.abs(a - b).max() <= tol
+    # in-plane rotation: separable kernel vs general kernel vs direct kernel
+    m = vt.utils.transform_matrix(rotation=(0, 33, 0), translation=(0.25, 1.5, -2.0), center=centre((n, n, n)))
+    sv.affine(m, output=out)
+    a = out.get()
+    assert sv.info().last_kernel == 3
+    sv.affine(m, output=out, _flags=_native.NO_ZSEP)
+    assert sv.info().last_kernel == 2
+    assert np.abs(a - out.get()).max() <= tol
+    sv.affine(m, output=out, _flags=_native.FORCE_DIRECT)
+    assert np.abs(a - out.get()).max() <= tol
     sv.close()
     out.free()

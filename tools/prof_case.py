@@ -1,0 +1,42 @@
+"""Run one resident-transform configuration repeatedly (for rocprofv3 kernel traces / PMC passes).
+
+    python3 tools/prof_case.py --size 512 --interp linear --angle 45 --iters 10 [--order rzxz] [--general]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import voltools_amd as vt  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--size', type=int, default=512)
+ap.add_argument('--interp', default='linear')
+ap.add_argument('--angle', type=float, default=45.0)
+ap.add_argument('--general', action='store_true', help='general 3-D rotation (25,-40,70) sxyz instead of in-plane')
+ap.add_argument('--iters', type=int, default=10)
+ap.add_argument('--flags', type=int, default=0)
+args = ap.parse_args()
+
+n = args.size
+vol = np.random.RandomState(0).random_sample((n, n, n)).astype(np.float32)
+sv = vt.StaticVolume(vol, interpolation=args.interp, device='gpu:0')
+out = vt.empty((n, n, n), device='gpu:0')
+c = np.divide(np.subtract((n, n, n), 1), 2, dtype=np.float32)
+if args.general:
+    m = vt.utils.transform_matrix(rotation=(25, -40, 70), rotation_order='sxyz', center=c)
+else:
+    m = vt.utils.transform_matrix(rotation=(0, args.angle, 0), rotation_order='rzxz', center=c)
+for _ in range(3):
+    sv.affine(m, output=out, _flags=args.flags)
+sv.synchronize()
+sv.timer_start()
+for _ in range(args.iters):
+    sv.affine(m, output=out, _flags=args.flags)
+ms = sv.timer_stop() / args.iters
+info = sv.info()
+print(f'{args.interp} {n}^3 angle={args.angle} general={args.general}: {ms:.4f} ms/launch, '
+      f'{n ** 3 / ms / 1e6:.1f} Gvox/s, {8.0 * n ** 3 / ms / 1e6:.1f} GB/s algorithmic, tile={tuple(info.last_tile)} '
+      f'box={tuple(info.last_lds_dims)} lds={info.last_lds_bytes} prefilter_ms={info.prefilter_ms:.3f}')

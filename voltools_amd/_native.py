@@ -45,6 +45,29 @@ class VolumeInfo(ctypes.Structure):
 _lib = None
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64;
+    if this library pulled in the system copy first and torch was imported afterwards, the process would hold
+    two HSA runtimes and torch would see no GPU.  When torch is installed (not necessarily imported) bind to
+    its copy -- same SONAME, so our DT_NEEDED resolves to it.  VT_HIP_RUNTIME=system disables this."""
+    import importlib.util
+    import sys
+    if os.environ.get('VT_HIP_RUNTIME', '') == 'system' or 'torch' in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], 'lib', 'libamdhip64.so')
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Load the library once; raises OSError when it has not been built."""
     global _lib
@@ -52,6 +75,7 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise OSError(f'{LIB_PATH} not found (run __graft_entry__.build())')
+    _preload_hip_runtime()
     L = ctypes.CDLL(LIB_PATH)
     c_int, c_void_p, c_size_t, c_i64 = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int64
     P = ctypes.POINTER

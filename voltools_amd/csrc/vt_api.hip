@@ -69,7 +69,9 @@ struct vt_volume {
     int64_t plane0 = 0;                // global index of resident plane 0
     int64_t gD = 0;                    // global depth
     int64_t out_plane0 = 0;            // global index of output plane 0
+    int P = 0;                         // row pitch of d_src in floats: W rounded up to 4, pad columns hold 0
     float* d_src = nullptr;
+    float* d_zeros = nullptr;          // 16 bytes of zeros: the border fetch target of the tiled kernel
     float* d_scratch_out = nullptr;    // staging for host outputs
     size_t scratch_elems = 0;
     hipStream_t stream = nullptr;
@@ -86,7 +88,7 @@ namespace {
 
 // Run the three passes X, Y, Z (reference order, transforms.py:305-307) on d_a, using d_b as the
 // ping-pong partner.  Returns which buffer holds the coefficients.
-int run_prefilter(float* d_a, float* d_b, int D, int H, int W, bool lo_interior_axis0, hipStream_t st, float** result)
+int run_prefilter(float* d_a, float* d_b, int D, int H, int W, int P, bool lo_interior_axis0, hipStream_t st, float** result)
 {
     float* cur = d_a;
     float* oth = d_b;
@@ -95,9 +97,9 @@ int run_prefilter(float* d_a, float* d_b, int D, int H, int W, bool lo_interior_
         const int axis = order[i];
         const bool interior = (axis == 0) && lo_interior_axis0;
         if (prefilter_axis_in_place_ok(axis, D, H, W)) {
-            VT_HIP(launch_prefilter_axis(axis, cur, cur, D, H, W, interior, st));
+            VT_HIP(launch_prefilter_axis(axis, cur, cur, D, H, W, P, interior, st));
         } else {
-            VT_HIP(launch_prefilter_axis(axis, cur, oth, D, H, W, interior, st));
+            VT_HIP(launch_prefilter_axis(axis, cur, oth, D, H, W, P, interior, st));
             float* t = cur; cur = oth; oth = t;
         }
     }
@@ -110,10 +112,16 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
 {
     const bool cubic = is_cubic(v->interp);
     const int64_t n_out = (int64_t)v->oD * v->oH * v->oW;
-    const bool vec4 = (v->W % 4 == 0) && ((reinterpret_cast<uintptr_t>(v->d_src) & 15) == 0);
-
     std::memcpy(p->m, m, sizeof(double) * 12);
-    p->sD = v->D; p->sH = v->H; p->sW = v->W;
+    p->sD = v->D; p->sH = v->H; p->sW = v->W; p->sP = v->P;
+    for (int r = 0; r < 3; ++r) {
+        // Q32.32 split of the depth-axis step m[r][0] (|m| < 4096 is checked below for tiled launches)
+        const double step = m[4 * r];
+        const double fl = std::floor(step);
+        p->inc_hi[r] = (std::fabs(step) < 2.0e9) ? (int32_t)fl : 0;
+        p->inc_lo[r] = (uint32_t)std::min(4294967295.0, std::floor((step - fl) * 4294967296.0 + 0.5));
+        if ((step - fl) * 4294967296.0 + 0.5 >= 4294967296.0) { p->inc_lo[r] = 0; p->inc_hi[r] += 1; }
+    }
     p->oD = v->oD; p->oH = v->oH; p->oW = v->oW;
     p->flags = flags & VT_KEEP_OUTSIDE;
     // skirt rule src + 0.5 in [0, dim) on the global volume, expressed on resident coordinates
@@ -121,7 +129,7 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
     p->vlo[1] = -0.5;                      p->vhi[1] = (double)v->H - 0.5;
     p->vlo[2] = -0.5;                      p->vhi[2] = (double)v->W - 0.5;
 
-    plan->kind = 1; plan->cfg = -1; plan->td = plan->th = plan->tw = 0; plan->lds_bytes = 0; plan->grid = 0; plan->vec4 = vec4;
+    plan->kind = 1; plan->cfg = -1; plan->td = plan->th = plan->tw = 0; plan->lds_bytes = 0; plan->grid = 0;
     bool want_tiled = n_out >= 64 * 64 * 64;
     if (flags & VT_FORCE_TILED) want_tiled = true;
     if (flags & VT_FORCE_DIRECT) want_tiled = false;
@@ -130,6 +138,9 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
     if (!want_tiled) return 0;
 
     const int halo2 = cubic ? 2 : 0;           // cubic taps reach one voxel further on each side
+    // axis-0-separable block form [1 0 0 tz; 0 a b ty; 0 c d tx] (rotations about axis 0, in-plane maps)
+    const bool zsep = !(flags & VT_NO_ZSEP) && m[0] == 1.0 && m[1] == 0.0 && m[2] == 0.0 && m[4] == 0.0 && m[8] == 0.0 &&
+                      std::fabs(m[3]) < 1.0e9;
     double best_cost = 1e300;
     for (int c = 0; c < tile_config_count(); ++c) {
         if (v->force_cfg >= 0 && c != v->force_cfg) continue;
@@ -143,8 +154,9 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
             if (!(ext < 4096.0)) { ok = false; break; }
             L[r] = (int)std::floor(ext) + 3 + halo2;       // floor(hi)-floor(lo) <= floor(ext)+1, +1 upper tap, +1 slack
         }
+        if (ok && zsep) L[0] = T[0] + 1 + halo2;           // exactly the planes d0+zoff-halo .. d0+TD+zoff+halo
         if (!ok) continue;
-        if (vec4) L[2] = (L[2] + 3 + 3) & ~3;              // origin aligned down by up to 3, stride multiple of 4
+        L[2] = (L[2] + 3 + 3) & ~3;                        // origin aligned down by up to 3, stride multiple of 4
         const int64_t bytes = (int64_t)L[0] * L[1] * L[2] * 4;
         if (bytes > v->lds_limit) continue;
         const int blocks_per_cu = (int)std::min<int64_t>(8, (160 * 1024) / bytes);
@@ -154,12 +166,17 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
         double cost = (double)bytes / vox * (blocks_per_cu >= 3 ? 1.0 : (blocks_per_cu == 2 ? 1.25 : 2.0));
         if (cost < best_cost) {
             best_cost = cost;
-            plan->kind = 2; plan->cfg = c; plan->td = T[0]; plan->th = T[1]; plan->tw = T[2];
+            plan->kind = zsep ? 3 : 2; plan->cfg = c; plan->td = T[0]; plan->th = T[1]; plan->tw = T[2];
             plan->lds_bytes = (int)bytes;
             p->Lz = L[0]; p->Ly = L[1]; p->Lx = L[2];
         }
     }
-    if (plan->kind != 2) return 0;             // footprint does not fit LDS: direct gather
+    if (plan->kind < 2) return 0;              // footprint does not fit LDS: direct gather
+    if (zsep) {
+        const double fl = std::floor(m[3]);
+        p->zoff = (int32_t)fl;
+        p->fz = (float)(m[3] - fl);
+    }
 
     const int T[3] = {plan->td, plan->th, plan->tw};
     for (int r = 0; r < 3; ++r) {
@@ -214,9 +231,9 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
             VT_HIP(hipMemcpyAsync(d_out, out, n_out * sizeof(float), hipMemcpyHostToDevice, v->stream));
     }
 
-    if (plan.kind == 2) {
-        VT_HIP(launch_affine_tiled(plan.cfg, v->interp, plan.vec4, v->d_src, d_out, p, plan.grid, plan.lds_bytes, v->stream));
-        v->last_kernel = 2;
+    if (plan.kind >= 2) {
+        VT_HIP(launch_affine_tiled(plan.cfg, v->interp, plan.kind == 3, v->d_src, d_out, v->d_zeros, p, plan.grid, plan.lds_bytes, v->stream));
+        v->last_kernel = plan.kind;
         v->last_tile[0] = plan.td; v->last_tile[1] = plan.th; v->last_tile[2] = plan.tw;
         v->last_lds[0] = p.Lz; v->last_lds[1] = p.Ly; v->last_lds[2] = p.Lx;
         v->last_lds_bytes = plan.lds_bytes; v->last_grid = plan.grid;
@@ -278,16 +295,29 @@ int create_common(int dev, int D, int H, int W, int interp, const float* data, i
     VT_HIPC(hipStreamCreateWithFlags(&v->stream, hipStreamDefault));
     VT_HIPC(hipEventCreate(&v->ev0));
     VT_HIPC(hipEventCreate(&v->ev1));
-    const size_t bytes = (size_t)D * H * W * sizeof(float);
+    // resident layout: rows padded to a multiple of 4 floats so every row starts 16-byte aligned (the tiled
+    // kernel stages with 16-byte direct-to-LDS loads); pad columns are zero = the border value
+    v->P = (W + 3) & ~3;
+    const size_t bytes = (size_t)D * H * v->P * sizeof(float);
     VT_HIPC(hipMalloc(reinterpret_cast<void**>(&v->d_src), bytes));
-    VT_HIPC(hipMemcpyAsync(v->d_src, data, bytes, (cflags & VT_SRC_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, v->stream));
+    VT_HIPC(hipMalloc(reinterpret_cast<void**>(&v->d_zeros), 256));
+    VT_HIPC(hipMemsetAsync(v->d_zeros, 0, 256, v->stream));
+    const hipMemcpyKind kind = (cflags & VT_SRC_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    if (v->P == W) {
+        VT_HIPC(hipMemcpyAsync(v->d_src, data, bytes, kind, v->stream));
+    } else {
+        VT_HIPC(hipMemsetAsync(v->d_src, 0, bytes, v->stream));
+        VT_HIPC(hipMemcpy2DAsync(v->d_src, (size_t)v->P * sizeof(float), data, (size_t)W * sizeof(float),
+                                 (size_t)W * sizeof(float), (size_t)D * H, kind, v->stream));
+    }
 
     if (is_filtered(interp)) {
         float* d_tmp = nullptr;
         VT_HIPC(hipMalloc(reinterpret_cast<void**>(&d_tmp), bytes));
+        if (v->P != W) { hipError_t em = hipMemsetAsync(d_tmp, 0, bytes, v->stream); if (em != hipSuccess) { hipFree(d_tmp); return cleanup(fail((int)em, "memset: %s", hipGetErrorString(em))); } }
         float* res = nullptr;
         hipEventRecord(v->ev0, v->stream);
-        rc = run_prefilter(v->d_src, d_tmp, D, H, W, (cflags & VT_SLAB_LO_INTERIOR) != 0, v->stream, &res);
+        rc = run_prefilter(v->d_src, d_tmp, D, H, W, v->P, (cflags & VT_SLAB_LO_INTERIOR) != 0, v->stream, &res);
         hipEventRecord(v->ev1, v->stream);
         hipError_t es = hipStreamSynchronize(v->stream);
         if (rc || es != hipSuccess) {
@@ -428,6 +458,7 @@ int vt_volume_destroy(vt_volume_t* v)
     hipSetDevice(v->dev);
     if (v->stream) hipStreamSynchronize(v->stream);
     if (v->d_src) hipFree(v->d_src);
+    if (v->d_zeros) hipFree(v->d_zeros);
     if (v->d_scratch_out) hipFree(v->d_scratch_out);
     if (v->ev0) hipEventDestroy(v->ev0);
     if (v->ev1) hipEventDestroy(v->ev1);
@@ -446,7 +477,7 @@ int vt_volume_info(const vt_volume_t* v, vt_volume_info_t* info)
     for (int i = 0; i < 3; ++i) { info->last_tile[i] = v->last_tile[i]; info->last_lds_dims[i] = v->last_lds[i]; }
     info->last_lds_bytes = v->last_lds_bytes; info->last_grid = v->last_grid;
     info->prefilter_ms = v->prefilter_ms;
-    info->resident_bytes = (uint64_t)v->D * v->H * v->W * sizeof(float);
+    info->resident_bytes = (uint64_t)v->D * v->H * v->P * sizeof(float);
     return 0;
 }
 
@@ -519,7 +550,7 @@ int vt_prefilter_inplace(int dev, float* d_volume, int D, int H, int W)
     float* d_tmp = nullptr;
     VT_HIP(hipMalloc(reinterpret_cast<void**>(&d_tmp), bytes));
     float* res = nullptr;
-    rc = run_prefilter(d_volume, d_tmp, D, H, W, false, nullptr, &res);
+    rc = run_prefilter(d_volume, d_tmp, D, H, W, W, false, nullptr, &res);
     if (!rc && res != d_volume) {
         hipError_t e = hipMemcpyAsync(d_volume, res, bytes, hipMemcpyDeviceToDevice, nullptr);
         if (e != hipSuccess) rc = fail((int)e, "copy back: %s", hipGetErrorString(e));

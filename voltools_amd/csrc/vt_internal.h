@@ -20,26 +20,30 @@ struct AffineParams {
     double pos[3];     // sum_c max(0, m[r][c]*(T_c-1))
     double vlo[3];     // valid source interval [vlo, vhi) per axis: the skirt rule src+0.5 in [0, dim)
     double vhi[3];
-    int32_t sD, sH, sW;        // resident source dims (storage)
+    int32_t inc_hi[3];         // Q32.32 split of m[r][0]: per-step increment along the tile's depth axis
+    uint32_t inc_lo[3];
+    int32_t sD, sH, sW;        // resident source dims
+    int32_t sP;                // row pitch of the resident source in floats (multiple of 4, pad columns are 0)
     int32_t oD, oH, oW;        // output dims
     int32_t nTd, nTh, nTw;     // output tile counts
     int32_t Lz, Ly, Lx;        // staged source box (floats); Lx is the LDS row stride
     int32_t flags;             // VT_KEEP_OUTSIDE
+    int32_t zoff;              // axis-0-separable launches: src_z = d + zoff + fz
+    float fz;
 };
 
 struct TilePlan {
-    int kind;            // 1 direct, 2 tiled
+    int kind;            // 1 direct, 2 tiled, 3 tiled axis-0-separable
     int cfg;             // index into the tile table
     int td, th, tw;
     int lds_bytes;
     int grid;
-    bool vec4;
 };
 
 // launchers (vt_kernels_affine.hip)
 int tile_config_count();
 void tile_config(int idx, int* td, int* th, int* tw);
-hipError_t launch_affine_tiled(int cfg, int interp, bool vec4, const float* src, float* out,
+hipError_t launch_affine_tiled(int cfg, int interp, bool zsep, const float* src, float* out, const float* zeros16,
                                const AffineParams& p, int grid, int lds_bytes, hipStream_t stream);
 hipError_t launch_affine_direct(int interp, const float* src, float* out, const AffineParams& p,
                                 hipStream_t stream);
@@ -47,7 +51,7 @@ hipError_t init_affine_kernels();   // raises the dynamic-LDS limit of every til
 
 // prefilter (vt_kernels_prefilter.hip).  src -> dst; `*in_place_ok` tells whether src == dst is legal.
 // axis: 0 (Z, stride H*W), 1 (Y, stride W), 2 (X, contiguous).
-hipError_t launch_prefilter_axis(int axis, const float* src, float* dst, int D, int H, int W,
+hipError_t launch_prefilter_axis(int axis, const float* src, float* dst, int D, int H, int W, int pitch,
                                  bool lo_interior, hipStream_t stream);
 bool prefilter_axis_in_place_ok(int axis, int D, int H, int W);
 

@@ -79,13 +79,13 @@ __device__ __forceinline__ float wave_sum(float t)
 // ---- X pass: one wave per contiguous line, NSEG segments of 64 samples in registers ----
 template <int NSEG>
 __global__ __launch_bounds__(256) void prefilter_x_scan(const float* __restrict__ src, float* __restrict__ dst,
-                                                         int W, int64_t nlines, int lo_interior)
+                                                         int W, int pitch, int64_t nlines, int lo_interior)
 {
     const int lane = threadIdx.x & 63;
     const int64_t line = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (line >= nlines) return;                       // wave-uniform
-    const float* s = src + line * W;
-    float* o = dst + line * W;
+    const float* s = src + line * pitch;
+    float* o = dst + line * pitch;
 
     float v[NSEG];
 #pragma unroll
@@ -218,10 +218,10 @@ bool prefilter_axis_in_place_ok(int axis, int D, int H, int W)
     return N <= kChunk;                               // single chunk: a lane reads its whole line first
 }
 
-hipError_t launch_prefilter_axis(int axis, const float* src, float* dst, int D, int H, int W,
+hipError_t launch_prefilter_axis(int axis, const float* src, float* dst, int D, int H, int W, int pitch,
                                  bool lo_interior, hipStream_t stream)
 {
-    const int64_t plane = (int64_t)H * W;
+    const int64_t plane = (int64_t)H * pitch;
     if (axis == 2 && W <= 2048) {
         const int64_t nlines = (int64_t)D * H;
         const int64_t blocks = (nlines + 3) / 4;
@@ -229,19 +229,19 @@ hipError_t launch_prefilter_axis(int axis, const float* src, float* dst, int D, 
         const int nseg = (W + 63) / 64;
         const dim3 g((unsigned)blocks), b(256);
         const int li = lo_interior ? 1 : 0;
-        if (nseg <= 1) hipLaunchKernelGGL(prefilter_x_scan<1>, g, b, 0, stream, src, dst, W, nlines, li);
-        else if (nseg <= 2) hipLaunchKernelGGL(prefilter_x_scan<2>, g, b, 0, stream, src, dst, W, nlines, li);
-        else if (nseg <= 4) hipLaunchKernelGGL(prefilter_x_scan<4>, g, b, 0, stream, src, dst, W, nlines, li);
-        else if (nseg <= 8) hipLaunchKernelGGL(prefilter_x_scan<8>, g, b, 0, stream, src, dst, W, nlines, li);
-        else if (nseg <= 16) hipLaunchKernelGGL(prefilter_x_scan<16>, g, b, 0, stream, src, dst, W, nlines, li);
-        else hipLaunchKernelGGL(prefilter_x_scan<32>, g, b, 0, stream, src, dst, W, nlines, li);
+        if (nseg <= 1) hipLaunchKernelGGL(prefilter_x_scan<1>, g, b, 0, stream, src, dst, W, pitch, nlines, li);
+        else if (nseg <= 2) hipLaunchKernelGGL(prefilter_x_scan<2>, g, b, 0, stream, src, dst, W, pitch, nlines, li);
+        else if (nseg <= 4) hipLaunchKernelGGL(prefilter_x_scan<4>, g, b, 0, stream, src, dst, W, pitch, nlines, li);
+        else if (nseg <= 8) hipLaunchKernelGGL(prefilter_x_scan<8>, g, b, 0, stream, src, dst, W, pitch, nlines, li);
+        else if (nseg <= 16) hipLaunchKernelGGL(prefilter_x_scan<16>, g, b, 0, stream, src, dst, W, pitch, nlines, li);
+        else hipLaunchKernelGGL(prefilter_x_scan<32>, g, b, 0, stream, src, dst, W, pitch, nlines, li);
         return hipGetLastError();
     }
     int N, nA, nB;
     int64_t es, sA, sB;
-    if (axis == 2) { N = W; es = 1; nA = H; sA = W; nB = D; sB = plane; }          // very wide lines: lanes along y
-    else if (axis == 1) { N = H; es = W; nA = W; sA = 1; nB = D; sB = plane; }
-    else { N = D; es = plane; nA = W; sA = 1; nB = H; sB = W; }
+    if (axis == 2) { N = W; es = 1; nA = H; sA = pitch; nB = D; sB = plane; }      // very wide lines: lanes along y
+    else if (axis == 1) { N = H; es = pitch; nA = W; sA = 1; nB = D; sB = plane; }
+    else { N = D; es = plane; nA = W; sA = 1; nB = H; sB = pitch; }
     const int nchunks = (N + kChunk - 1) / kChunk;
     const int64_t waves = (int64_t)((nA + 63) / 64) * nB * nchunks;
     const int64_t blocks = (waves + 3) / 4;
