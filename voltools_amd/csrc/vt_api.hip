@@ -141,6 +141,66 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
     // axis-0-separable block form [1 0 0 tz; 0 a b ty; 0 c d tx] (rotations about axis 0, in-plane maps)
     const bool zsep = !(flags & VT_NO_ZSEP) && m[0] == 1.0 && m[1] == 0.0 && m[2] == 0.0 && m[4] == 0.0 && m[8] == 0.0 &&
                       std::fabs(m[3]) < 1.0e9;
+    p->zero_off = ((v->W + 3) & ~3) * 4;
+    if (zsep && !(flags & VT_NO_MARCH) && (int64_t)v->H * v->P * 4 < 0x7fffffffLL) {
+        // marching kernel: pick the in-plane tile with the least staged bytes per pixel
+        const double fl = std::floor(m[3]);
+        double best = 1e300;
+        for (int c = 0; c < march_config_count(); ++c) {
+            if (v->force_cfg >= 0 && c != v->force_cfg) continue;
+            int th, tw, g;
+            march_config(c, &th, &tw, &g);
+            const int T[3] = {1, th, tw};
+            int L[3] = {0, 0, 0};
+            bool ok = true;
+            for (int r = 1; r < 3 && ok; ++r) {
+                double ext = 0;
+                for (int k = 1; k < 3; ++k) ext += std::fabs(m[4 * r + k]) * (T[k] - 1);
+                if (!(ext < 4096.0)) { ok = false; break; }
+                L[r] = (int)std::floor(ext) + 3 + halo2;
+            }
+            if (!ok) continue;
+            L[2] = (L[2] + 3 + 3) & ~3;
+            const int ring = 2 * g + halo2 + 1;
+            const int64_t bytes = (int64_t)ring * L[1] * L[2] * 4;
+            if (L[1] * (L[2] / 4) > 1024 || bytes > v->lds_limit) continue;
+            const int blocks_per_cu = (int)std::min<int64_t>(8, (160 * 1024) / bytes);
+            double cost = (double)(L[1] * L[2]) / (th * tw) * (blocks_per_cu >= 3 ? 1.0 : (blocks_per_cu == 2 ? 1.15 : 1.6));
+            if (tw < 32) cost *= 1.1;                      // 64-byte store segments
+            if (cost < best) {
+                best = cost;
+                plan->kind = 4; plan->cfg = c; plan->td = g; plan->th = th; plan->tw = tw;
+                plan->lds_bytes = (int)bytes;
+                p->Lz = ring; p->Ly = L[1]; p->Lx = L[2];
+            }
+        }
+        if (plan->kind == 4) {
+            const int T[3] = {1, plan->th, plan->tw};
+            for (int r = 0; r < 3; ++r) {
+                double neg = 0, pos = 0;
+                for (int k = 1; k < 3; ++k) {
+                    const double e = m[4 * r + k] * (T[k] - 1);
+                    if (e < 0) neg += e; else pos += e;
+                }
+                p->neg[r] = neg; p->pos[r] = pos;
+            }
+            p->zoff = (int32_t)fl;
+            p->fz = (float)(m[3] - fl);
+            p->nTh = (v->oH + plan->th - 1) / plan->th;
+            p->nTw = (v->oW + plan->tw - 1) / plan->tw;
+            const int g = plan->td;
+            const int64_t inplane = (int64_t)p->nTh * p->nTw;
+            int64_t nchunks = std::max<int64_t>(1, std::min<int64_t>((v->oD + 31) / 32, (8 * (int64_t)v->cu_count + inplane - 1) / inplane));
+            int dch = (int)((v->oD + nchunks - 1) / nchunks);
+            dch = ((dch + g - 1) / g) * g;
+            nchunks = (v->oD + dch - 1) / dch;
+            p->dch = dch;
+            p->nTd = (int)nchunks;
+            const int64_t grid = inplane * nchunks;
+            if (grid <= 0x7fffffffLL) { plan->grid = (int)grid; return 0; }
+            plan->kind = 1;
+        }
+    }
     double best_cost = 1e300;
     for (int c = 0; c < tile_config_count(); ++c) {
         if (v->force_cfg >= 0 && c != v->force_cfg) continue;
@@ -231,7 +291,13 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
             VT_HIP(hipMemcpyAsync(d_out, out, n_out * sizeof(float), hipMemcpyHostToDevice, v->stream));
     }
 
-    if (plan.kind >= 2) {
+    if (plan.kind == 4) {
+        VT_HIP(launch_affine_march(plan.cfg, v->interp, v->d_src, d_out, p, plan.grid, plan.lds_bytes, v->stream));
+        v->last_kernel = 4;
+        v->last_tile[0] = plan.td; v->last_tile[1] = plan.th; v->last_tile[2] = plan.tw;
+        v->last_lds[0] = p.Lz; v->last_lds[1] = p.Ly; v->last_lds[2] = p.Lx;
+        v->last_lds_bytes = plan.lds_bytes; v->last_grid = plan.grid;
+    } else if (plan.kind >= 2) {
         VT_HIP(launch_affine_tiled(plan.cfg, v->interp, plan.kind == 3, v->d_src, d_out, v->d_zeros, p, plan.grid, plan.lds_bytes, v->stream));
         v->last_kernel = plan.kind;
         v->last_tile[0] = plan.td; v->last_tile[1] = plan.th; v->last_tile[2] = plan.tw;
@@ -297,24 +363,23 @@ int create_common(int dev, int D, int H, int W, int interp, const float* data, i
     VT_HIPC(hipEventCreate(&v->ev1));
     // resident layout: rows padded to a multiple of 4 floats so every row starts 16-byte aligned (the tiled
     // kernel stages with 16-byte direct-to-LDS loads); pad columns are zero = the border value
-    v->P = (W + 3) & ~3;
+    v->P = ((W + 3) & ~3) + 4;         // + one guaranteed zero vector per row (border fetch target)
     const size_t bytes = (size_t)D * H * v->P * sizeof(float);
     VT_HIPC(hipMalloc(reinterpret_cast<void**>(&v->d_src), bytes));
     VT_HIPC(hipMalloc(reinterpret_cast<void**>(&v->d_zeros), 256));
     VT_HIPC(hipMemsetAsync(v->d_zeros, 0, 256, v->stream));
     const hipMemcpyKind kind = (cflags & VT_SRC_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    if (v->P == W) {
-        VT_HIPC(hipMemcpyAsync(v->d_src, data, bytes, kind, v->stream));
-    } else {
-        VT_HIPC(hipMemsetAsync(v->d_src, 0, bytes, v->stream));
-        VT_HIPC(hipMemcpy2DAsync(v->d_src, (size_t)v->P * sizeof(float), data, (size_t)W * sizeof(float),
-                                 (size_t)W * sizeof(float), (size_t)D * H, kind, v->stream));
-    }
+    VT_HIPC(hipMemsetAsync(v->d_src, 0, bytes, v->stream));
+    VT_HIPC(hipMemcpy2DAsync(v->d_src, (size_t)v->P * sizeof(float), data, (size_t)W * sizeof(float),
+                             (size_t)W * sizeof(float), (size_t)D * H, kind, v->stream));
 
     if (is_filtered(interp)) {
         float* d_tmp = nullptr;
         VT_HIPC(hipMalloc(reinterpret_cast<void**>(&d_tmp), bytes));
-        if (v->P != W) { hipError_t em = hipMemsetAsync(d_tmp, 0, bytes, v->stream); if (em != hipSuccess) { hipFree(d_tmp); return cleanup(fail((int)em, "memset: %s", hipGetErrorString(em))); } }
+        {
+            hipError_t em = hipMemsetAsync(d_tmp, 0, bytes, v->stream);
+            if (em != hipSuccess) { hipFree(d_tmp); return cleanup(fail((int)em, "memset: %s", hipGetErrorString(em))); }
+        }
         float* res = nullptr;
         hipEventRecord(v->ev0, v->stream);
         rc = run_prefilter(v->d_src, d_tmp, D, H, W, v->P, (cflags & VT_SLAB_LO_INTERIOR) != 0, v->stream, &res);

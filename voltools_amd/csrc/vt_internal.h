@@ -30,10 +30,12 @@ struct AffineParams {
     int32_t flags;             // VT_KEEP_OUTSIDE
     int32_t zoff;              // axis-0-separable launches: src_z = d + zoff + fz
     float fz;
+    int32_t dch;               // marching kernel: output planes per workgroup
+    int32_t zero_off;          // byte offset, inside any source plane, of a 16-byte vector of zeros (row pad)
 };
 
 struct TilePlan {
-    int kind;            // 1 direct, 2 tiled, 3 tiled axis-0-separable
+    int kind;            // 1 direct, 2 tiled, 3 tiled axis-0-separable, 4 marching axis-0-separable
     int cfg;             // index into the tile table
     int td, th, tw;
     int lds_bytes;
@@ -45,6 +47,10 @@ int tile_config_count();
 void tile_config(int idx, int* td, int* th, int* tw);
 hipError_t launch_affine_tiled(int cfg, int interp, bool zsep, const float* src, float* out, const float* zeros16,
                                const AffineParams& p, int grid, int lds_bytes, hipStream_t stream);
+int march_config_count();
+void march_config(int idx, int* th, int* tw, int* g);
+hipError_t launch_affine_march(int cfg, int interp, const float* src, float* out, const AffineParams& p,
+                               int grid, int lds_bytes, hipStream_t stream);
 hipError_t launch_affine_direct(int interp, const float* src, float* out, const AffineParams& p,
                                 hipStream_t stream);
 hipError_t init_affine_kernels();   // raises the dynamic-LDS limit of every tiled instantiation

@@ -454,6 +454,222 @@ __global__ __launch_bounds__(256) void affine_tiled_zsep(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------
+// axis-0-separable *marching* kernel
+// ---------------------------------------------------------------------------------------------------
+// Same block-form matrices as affine_tiled_zsep, organised as a software pipeline along axis 0.
+// A workgroup owns one TH x TW in-plane output tile and marches through `dch` output planes:
+//   * per-thread set-up happens once: in-plane tap origin, fractions and weights of its NPIX pixels, and
+//     the byte offsets of the 16-byte source vectors it is responsible for staging (the in-plane box of
+//     the tile is the same for every plane);
+//   * source planes stream through a ring of R = 2G + 2*HALO + 1 LDS slots.  While the workgroup computes
+//     a group of G output planes, the `buffer_load ... lds` (direct-to-LDS) loads of the next G source
+//     planes are in flight -- each costs one instruction and no VALU work: offsets are precomputed,
+//     out-of-volume vectors point at a zero vector that the resident layout keeps at the end of every row;
+//   * every source plane's in-plane partial (bilinear blend / 16-tap B-spline sum) is computed exactly once
+//     per pixel and carried in registers across the 2 (4) output planes that use it;
+//   * one s_barrier per G planes; the wait that precedes it is a *counted* vmcnt so the output stores of
+//     the previous group stay in flight.
+// Per output voxel: 4 (linear) / 16 (cubic) LDS reads, ~12 / ~30 VALU instructions, one 4-byte store.
+template <int KIND, int TH, int TW, int G>
+__global__ __launch_bounds__(256) void affine_march_zsep(const float* __restrict__ src, float* __restrict__ out,
+                                                          const AffineParams p)
+{
+    static_assert(256 % TW == 0 && TH % (256 / TW) == 0, "tile/thread mapping");
+    constexpr bool CUBIC = KIND != 0;
+    constexpr int HALO = CUBIC ? 1 : 0;
+    constexpr int NC = 2 * HALO + 1;              // carried partials per pixel
+    constexpr int R = 2 * G + 2 * HALO + 1;       // ring slots
+    constexpr int RP = 256 / TW;
+    constexpr int NPIX = TH / RP;
+    constexpr int MAXIT = 4;                      // in-plane box <= 1024 vectors (16 KiB per plane)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x;
+    const int t = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int tw_i = t % p.nTw;
+    const int t2 = t / p.nTw;
+    const int th_i = t2 % p.nTh;
+    const int chunk = t2 / p.nTh;
+    const int h0 = th_i * TH, w0 = tw_i * TW;
+    const int d_begin = chunk * p.dch;
+    const int d_end = min(d_begin + p.dch, p.oD);
+
+    // in-plane footprint (rows 1, 2; column 0 of the matrix is zero)
+    double base[3], lo[3], hi[3];
+    bool any_valid = true, all_valid = true;
+#pragma unroll
+    for (int r = 1; r < 3; ++r) {
+        base[r] = fma(p.m[4 * r + 1], (double)h0, fma(p.m[4 * r + 2], (double)w0, p.m[4 * r + 3]));
+        lo[r] = base[r] + p.neg[r];
+        hi[r] = base[r] + p.pos[r];
+        any_valid = any_valid && (hi[r] >= p.vlo[r]) && (lo[r] < p.vhi[r]);
+        all_valid = all_valid && (lo[r] >= p.vlo[r]) && (hi[r] < p.vhi[r]);
+    }
+    const double z_lo = (double)d_begin + p.m[3], z_hi = (double)(d_end - 1) + p.m[3];
+    any_valid = any_valid && (z_hi >= p.vlo[0]) && (z_lo < p.vhi[0]);
+    all_valid = all_valid && (z_lo >= p.vlo[0]) && (z_hi < p.vhi[0]);
+    const bool full_tile = (h0 + TH <= p.oH) && (w0 + TW <= p.oW) && ((d_end - d_begin) % G == 0);
+    const bool fast = all_valid && full_tile;     // unconditional stores: their count per group is exact
+    const bool keep = (p.flags & VT_KEEP_OUTSIDE) != 0;
+    const int64_t ostride = (int64_t)p.oH * p.oW;
+    const int kw = tid % TW;
+    const int jh0 = tid / TW;
+
+    if (!any_valid) {
+        if (!keep) {
+#pragma unroll
+            for (int px = 0; px < NPIX; ++px) {
+                const int h = h0 + jh0 + px * RP, w = w0 + kw;
+                if (h < p.oH && w < p.oW) {
+                    float* optr = out + ((int64_t)d_begin * p.oH + h) * p.oW + w;
+                    for (int d = d_begin; d < d_end; ++d, optr += ostride) *optr = 0.0f;
+                }
+            }
+        }
+        return;
+    }
+
+    const int o1 = (int)floor(lo[1]) - HALO;
+    const int o2 = ((int)floor(lo[2]) - HALO) & ~3;
+    const int Lx = p.Lx, Ly = p.Ly;
+    const int nvx = Lx >> 2;
+    const int nvec = Ly * nvx;                    // 16-byte vectors per plane
+    const int plane_floats = Ly * Lx;
+    const int nit = (nvec + 255) >> 8;            // <= MAXIT (host-checked)
+
+    // staging descriptors: byte offset inside a source plane of each vector this thread loads
+    int voff[MAXIT];
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int v = tid + 256 * it;
+        const int y = v / nvx;
+        const int cx = v - y * nvx;
+        const int gy = o1 + y, gx = o2 + 4 * cx;
+        const bool ok = (unsigned)gy < (unsigned)p.sH && (unsigned)gx < (unsigned)p.sP;
+        voff[it] = ok ? (gy * p.sP + gx) * 4 : p.zero_off;
+    }
+    const int wave_first = __builtin_amdgcn_readfirstlane(tid & ~63);
+    const int64_t plane_bytes = (int64_t)p.sH * p.sP * 4;
+
+    auto issue_plane = [&](int P, int slot) {
+        const bool plane_ok = (unsigned)P < (unsigned)p.sD;
+        const char* pbase = reinterpret_cast<const char*>(src) + (plane_ok ? (int64_t)P * plane_bytes : 0);
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pbase), 0, (int)plane_bytes, 0x00020000);
+        float* dst = lds + slot * plane_floats + 4 * wave_first;
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            if (it < nit) {
+                const int vb = wave_first + 256 * it;
+                if (vb < nvec) {                              // wave-uniform
+                    const int off = plane_ok ? voff[it] : p.zero_off;
+                    if (tid + 256 * it < nvec)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + 1024 * it),
+                                                                 16, off, 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    // gather descriptors of this thread's pixels
+    int qoff[NPIX];
+    float fy[NPIX], fx[NPIX];
+    float wy[NPIX][4], wx[NPIX][4];
+    bool in_yx[NPIX];
+    float* optr[NPIX];
+    const double by = base[1] - (double)o1, bx = base[2] - (double)o2;
+#pragma unroll
+    for (int px = 0; px < NPIX; ++px) {
+        const int j = jh0 + px * RP;
+        const double sy = fma(p.m[5], (double)j, fma(p.m[6], (double)kw, by));
+        const double sx = fma(p.m[9], (double)j, fma(p.m[10], (double)kw, bx));
+        const double fyd = floor(sy), fxd = floor(sx);
+        fy[px] = (float)(sy - fyd);
+        fx[px] = (float)(sx - fxd);
+        qoff[px] = __mul24((int)fyd - HALO, Lx) + ((int)fxd - HALO);
+        if constexpr (CUBIC) { cubic_weights<KIND == 2>(fy[px], wy[px]); cubic_weights<KIND == 2>(fx[px], wx[px]); }
+        const double ey = sy + (double)o1, ex = sx + (double)o2;
+        in_yx[px] = (h0 + j < p.oH) && (w0 + kw < p.oW) &&
+                    (all_valid || ((ey >= p.vlo[1]) && (ey < p.vhi[1]) && (ex >= p.vlo[2]) && (ex < p.vhi[2])));
+        optr[px] = out + ((int64_t)d_begin * p.oH + (h0 + j)) * p.oW + (w0 + kw);
+    }
+    const bool in_tile_yx[1] = {true};
+    (void)in_tile_yx;
+    const float fz = p.fz;
+    float wz[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (CUBIC) cubic_weights<KIND == 2>(fz, wz);
+
+    // ---- pipeline ----
+    int P_next = d_begin + p.zoff - HALO;         // next source plane to stage
+    int slot_next = 0;
+    for (int c = 0; c < G + 2 * HALO + 1; ++c) {  // prologue: everything the first group needs
+        issue_plane(P_next, slot_next);
+        ++P_next;
+        slot_next = (slot_next + 1 == R) ? 0 : slot_next + 1;
+    }
+    float carry[NPIX][NC];
+    int slot_cur = 0;                             // slot of source plane zs(d) - HALO
+    bool first = true;
+    for (int d = d_begin; d < d_end; d += G) {
+        // my direct-to-LDS loads for this group have landed (the previous group's stores may stay in flight)
+        if (fast && !first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * NPIX) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();             // everyone's loads landed; everyone is done with the slots reused next
+        if (d + G < d_end) {
+            for (int c = 0; c < G; ++c) {
+                issue_plane(P_next, slot_next);
+                ++P_next;
+                slot_next = (slot_next + 1 == R) ? 0 : slot_next + 1;
+            }
+        }
+        if (first) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int sl = (slot_cur + c >= R) ? slot_cur + c - R : slot_cur + c;
+                const float* pl = lds + sl * plane_floats;
+#pragma unroll
+                for (int px = 0; px < NPIX; ++px)
+                    carry[px][c] = plane_partial<KIND>(pl + qoff[px], Lx, fy[px], fx[px], wy[px], wx[px]);
+            }
+            first = false;
+        }
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            int sl = slot_cur + NC + i;
+            sl = (sl >= R) ? sl - R : sl;
+            const float* pl = lds + sl * plane_floats;
+            bool z_ok = true;
+            if (!fast) {
+                const double ez = (double)(d + i) + p.m[3];
+                z_ok = (d + i < d_end) && (ez >= p.vlo[0]) && (ez < p.vhi[0]);
+            }
+#pragma unroll
+            for (int px = 0; px < NPIX; ++px) {
+                const float pn = plane_partial<KIND>(pl + qoff[px], Lx, fy[px], fx[px], wy[px], wx[px]);
+                float val;
+                if constexpr (!CUBIC) {
+                    val = fmaf(fz, pn - carry[px][0], carry[px][0]);
+                    carry[px][0] = pn;
+                } else {
+                    val = wz[0] * carry[px][0];
+                    val = fmaf(wz[1], carry[px][1], val);
+                    val = fmaf(wz[2], carry[px][2], val);
+                    val = fmaf(wz[3], pn, val);
+                    carry[px][0] = carry[px][1]; carry[px][1] = carry[px][2]; carry[px][2] = pn;
+                }
+                if (fast) optr[px][0] = val;
+                else if (d + i < d_end && h0 + jh0 + px * RP < p.oH && w0 + kw < p.oW) {
+                    if (in_yx[px] && z_ok) optr[px][0] = val;
+                    else if (!keep) optr[px][0] = 0.0f;
+                }
+                optr[px] += ostride;
+            }
+        }
+        slot_cur += G;
+        slot_cur = (slot_cur >= R) ? slot_cur - R : slot_cur;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // direct kernel: one thread per output voxel, taps from global memory with explicit border tests
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float fetch0(const float* __restrict__ src, const AffineParams& p, int z, int y, int x)
@@ -569,6 +785,36 @@ static tiled_fn tiled_entry(int cfg, int kind, bool zsep)
     }
 }
 
+typedef void (*march_fn)(const float*, float*, const AffineParams);
+struct MarchCfg { int th, tw, g; };
+static const MarchCfg kMarch[] = {
+    {16, 32, 4},    // 0: two pixels per thread, 128-byte store segments
+    {8, 32, 4},     // 1: smaller in-plane box
+    {16, 16, 4},    // 2: smallest box for 45-degree rotations
+    {16, 32, 2},    // 3: shallower ring (more workgroups per CU)
+};
+int march_config_count() { return (int)(sizeof(kMarch) / sizeof(kMarch[0])); }
+void march_config(int idx, int* th, int* tw, int* g) { *th = kMarch[idx].th; *tw = kMarch[idx].tw; *g = kMarch[idx].g; }
+
+template <int TH, int TW, int G>
+static march_fn pick_march(int kind)
+{
+    switch (kind) {
+        case 0: return affine_march_zsep<0, TH, TW, G>;
+        case 1: return affine_march_zsep<1, TH, TW, G>;
+        default: return affine_march_zsep<2, TH, TW, G>;
+    }
+}
+static march_fn march_entry(int cfg, int kind)
+{
+    switch (cfg) {
+        case 0: return pick_march<16, 32, 4>(kind);
+        case 1: return pick_march<8, 32, 4>(kind);
+        case 2: return pick_march<16, 16, 4>(kind);
+        default: return pick_march<16, 32, 2>(kind);
+    }
+}
+
 static int interp_kind(int interp)
 {
     switch (interp) {
@@ -588,7 +834,21 @@ hipError_t init_affine_kernels()
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 if (e != hipSuccess) return e;
             }
+    for (int cfg = 0; cfg < march_config_count(); ++cfg)
+        for (int kind = 0; kind < 3; ++kind) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(march_entry(cfg, kind)),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+        }
     return hipSuccess;
+}
+
+hipError_t launch_affine_march(int cfg, int interp, const float* src, float* out, const AffineParams& p,
+                               int grid, int lds_bytes, hipStream_t stream)
+{
+    march_fn fn = march_entry(cfg, interp_kind(interp));
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds_bytes, stream, src, out, p);
+    return hipGetLastError();
 }
 
 hipError_t launch_affine_tiled(int cfg, int interp, bool zsep, const float* src, float* out, const float* zeros16,
