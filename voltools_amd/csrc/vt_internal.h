@@ -48,7 +48,7 @@ void tile_config(int idx, int* td, int* th, int* tw);
 hipError_t launch_affine_tiled(int cfg, int interp, bool zsep, const float* src, float* out, const float* zeros16,
                                const AffineParams& p, int grid, int lds_bytes, hipStream_t stream);
 int march_config_count();
-void march_config(int idx, int* th, int* tw, int* g);
+void march_config(int idx, int* th, int* tw, int* g, int* la);
 hipError_t launch_affine_march(int cfg, int interp, const float* src, float* out, const AffineParams& p,
                                int grid, int lds_bytes, hipStream_t stream);
 hipError_t launch_affine_direct(int interp, const float* src, float* out, const AffineParams& p,

@@ -470,7 +470,25 @@ __global__ __launch_bounds__(256) void affine_tiled_zsep(const float* __restrict
 //   * one s_barrier per G planes; the wait that precedes it is a *counted* vmcnt so the output stores of
 //     the previous group stay in flight.
 // Per output voxel: 4 (linear) / 16 (cubic) LDS reads, ~12 / ~30 VALU instructions, one 4-byte store.
-template <int KIND, int TH, int TW, int G>
+// wait until at most n of this wave's vector-memory operations are outstanding (n is wave-uniform, the
+// instruction needs an immediate)
+__device__ __forceinline__ void wait_vmcnt_le(int n)
+{
+#define VT_WCASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (n) {
+        VT_WCASE(0) VT_WCASE(1) VT_WCASE(2) VT_WCASE(3) VT_WCASE(4) VT_WCASE(5) VT_WCASE(6) VT_WCASE(7)
+        VT_WCASE(8) VT_WCASE(9) VT_WCASE(10) VT_WCASE(11) VT_WCASE(12) VT_WCASE(13) VT_WCASE(14) VT_WCASE(15)
+        VT_WCASE(16) VT_WCASE(17) VT_WCASE(18) VT_WCASE(19) VT_WCASE(20) VT_WCASE(21) VT_WCASE(22) VT_WCASE(23)
+        VT_WCASE(24) VT_WCASE(25) VT_WCASE(26) VT_WCASE(27) VT_WCASE(28) VT_WCASE(29) VT_WCASE(30) VT_WCASE(31)
+        VT_WCASE(32) VT_WCASE(33) VT_WCASE(34) VT_WCASE(35) VT_WCASE(36) VT_WCASE(37) VT_WCASE(38) VT_WCASE(39)
+        VT_WCASE(40) VT_WCASE(41) VT_WCASE(42) VT_WCASE(43) VT_WCASE(44) VT_WCASE(45) VT_WCASE(46) VT_WCASE(47)
+        VT_WCASE(48) VT_WCASE(49) VT_WCASE(50) VT_WCASE(51) VT_WCASE(52) VT_WCASE(53) VT_WCASE(54) VT_WCASE(55)
+        default: asm volatile("s_waitcnt vmcnt(56)" ::: "memory"); break;
+    }
+#undef VT_WCASE
+}
+
+template <int KIND, int TH, int TW, int G, int LA>
 __global__ __launch_bounds__(256) void affine_march_zsep(const float* __restrict__ src, float* __restrict__ out,
                                                           const AffineParams p)
 {
@@ -478,7 +496,7 @@ __global__ __launch_bounds__(256) void affine_march_zsep(const float* __restrict
     constexpr bool CUBIC = KIND != 0;
     constexpr int HALO = CUBIC ? 1 : 0;
     constexpr int NC = 2 * HALO + 1;              // carried partials per pixel
-    constexpr int R = 2 * G + 2 * HALO + 1;       // ring slots
+    constexpr int R = (LA + 1) * G + 2 * HALO + 1;   // ring slots: live group + LA groups in flight
     constexpr int RP = 256 / TW;
     constexpr int NPIX = TH / RP;
     constexpr int MAXIT = 4;                      // in-plane box <= 1024 vectors (16 KiB per plane)
@@ -508,9 +526,10 @@ __global__ __launch_bounds__(256) void affine_march_zsep(const float* __restrict
     const double z_lo = (double)d_begin + p.m[3], z_hi = (double)(d_end - 1) + p.m[3];
     any_valid = any_valid && (z_hi >= p.vlo[0]) && (z_lo < p.vhi[0]);
     all_valid = all_valid && (z_lo >= p.vlo[0]) && (z_hi < p.vhi[0]);
-    const bool full_tile = (h0 + TH <= p.oH) && (w0 + TW <= p.oW) && ((d_end - d_begin) % G == 0);
-    const bool fast = all_valid && full_tile;     // unconditional stores: their count per group is exact
     const bool keep = (p.flags & VT_KEEP_OUTSIDE) != 0;
+    // every lane of the workgroup stores exactly one value per pixel and plane -> the number of stores a wave
+    // has in flight is known, and the wait before the barrier can leave them (and later loads) outstanding
+    const bool exact_stores = (h0 + TH <= p.oH) && (w0 + TW <= p.oW) && ((d_end - d_begin) % G == 0) && (all_valid || !keep);
     const int64_t ostride = (int64_t)p.oH * p.oW;
     const int kw = tid % TW;
     const int jh0 = tid / TW;
@@ -535,7 +554,6 @@ __global__ __launch_bounds__(256) void affine_march_zsep(const float* __restrict
     const int nvx = Lx >> 2;
     const int nvec = Ly * nvx;                    // 16-byte vectors per plane
     const int plane_floats = Ly * Lx;
-    const int nit = (nvec + 255) >> 8;            // <= MAXIT (host-checked)
 
     // staging descriptors: byte offset inside a source plane of each vector this thread loads
     int voff[MAXIT];
@@ -549,23 +567,28 @@ __global__ __launch_bounds__(256) void affine_march_zsep(const float* __restrict
         voff[it] = ok ? (gy * p.sP + gx) * 4 : p.zero_off;
     }
     const int wave_first = __builtin_amdgcn_readfirstlane(tid & ~63);
-    const int64_t plane_bytes = (int64_t)p.sH * p.sP * 4;
+    int nit_w = 0;                                // direct-to-LDS loads this wave issues per plane
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) nit_w += (wave_first + 256 * it < nvec) ? 1 : 0;
+    const int plane_bytes = p.sH * p.sP * 4;      // < 2^31 (host-checked)
+    // one buffer descriptor for the whole chunk, based at the first resident plane it touches; the plane is
+    // selected with the scalar offset operand
+    const int P_first = d_begin + p.zoff - HALO;
+    const int P_base = max(0, min(P_first, p.sD - 1));
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(src) + (int64_t)P_base * plane_bytes), 0, 0x7fffffff, 0x00020000);
 
     auto issue_plane = [&](int P, int slot) {
         const bool plane_ok = (unsigned)P < (unsigned)p.sD;
-        const char* pbase = reinterpret_cast<const char*>(src) + (plane_ok ? (int64_t)P * plane_bytes : 0);
-        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pbase), 0, (int)plane_bytes, 0x00020000);
+        const int soff = plane_ok ? (P - P_base) * plane_bytes : 0;
         float* dst = lds + slot * plane_floats + 4 * wave_first;
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
-            if (it < nit) {
-                const int vb = wave_first + 256 * it;
-                if (vb < nvec) {                              // wave-uniform
-                    const int off = plane_ok ? voff[it] : p.zero_off;
-                    if (tid + 256 * it < nvec)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + 1024 * it),
-                                                                 16, off, 0, 0, 0);
-                }
+            if (wave_first + 256 * it < nvec) {               // wave-uniform
+                const int off = plane_ok ? voff[it] : p.zero_off;
+                if (tid + 256 * it < nvec)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + 1024 * it),
+                                                             16, off, soff, 0, 0);
             }
         }
     };
@@ -588,40 +611,42 @@ __global__ __launch_bounds__(256) void affine_march_zsep(const float* __restrict
         qoff[px] = __mul24((int)fyd - HALO, Lx) + ((int)fxd - HALO);
         if constexpr (CUBIC) { cubic_weights<KIND == 2>(fy[px], wy[px]); cubic_weights<KIND == 2>(fx[px], wx[px]); }
         const double ey = sy + (double)o1, ex = sx + (double)o2;
-        in_yx[px] = (h0 + j < p.oH) && (w0 + kw < p.oW) &&
-                    (all_valid || ((ey >= p.vlo[1]) && (ey < p.vhi[1]) && (ex >= p.vlo[2]) && (ex < p.vhi[2])));
+        in_yx[px] = all_valid || ((ey >= p.vlo[1]) && (ey < p.vhi[1]) && (ex >= p.vlo[2]) && (ex < p.vhi[2]));
         optr[px] = out + ((int64_t)d_begin * p.oH + (h0 + j)) * p.oW + (w0 + kw);
     }
-    const bool in_tile_yx[1] = {true};
-    (void)in_tile_yx;
     const float fz = p.fz;
     float wz[4] = {0.f, 0.f, 0.f, 0.f};
     if constexpr (CUBIC) cubic_weights<KIND == 2>(fz, wz);
 
     // ---- pipeline ----
-    int P_next = d_begin + p.zoff - HALO;         // next source plane to stage
+    // order of a wave's vector-memory operations:  loads(g0 .. g0+LA-1) | [loads(g+LA) stores(g)] for g = g0, g0+1, ...
+    // => when group g is about to be computed, everything issued after loads(g) may stay outstanding:
+    //    (LA-1) groups of loads and, from the second iteration on, LA-1 ... groups of stores.
+    int P_next = P_first;                         // next source plane to stage
     int slot_next = 0;
-    for (int c = 0; c < G + 2 * HALO + 1; ++c) {  // prologue: everything the first group needs
-        issue_plane(P_next, slot_next);
-        ++P_next;
-        slot_next = (slot_next + 1 == R) ? 0 : slot_next + 1;
-    }
+    auto issue_planes = [&](int count) {
+        for (int c = 0; c < count; ++c) {
+            issue_plane(P_next, slot_next);
+            ++P_next;
+            slot_next = (slot_next + 1 == R) ? 0 : slot_next + 1;
+        }
+    };
+    const int ngroups = (d_end - d_begin + G - 1) / G;
+    issue_planes(G + 2 * HALO + 1);               // group 0 (with its halo planes)
+    for (int a = 1; a < LA; ++a) issue_planes(G); // groups 1 .. LA-1
+    const int loads_per_group = G * nit_w;
     float carry[NPIX][NC];
     int slot_cur = 0;                             // slot of source plane zs(d) - HALO
-    bool first = true;
-    for (int d = d_begin; d < d_end; d += G) {
-        // my direct-to-LDS loads for this group have landed (the previous group's stores may stay in flight)
-        if (fast && !first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * NPIX) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int g = 0;
+    for (int d = d_begin; d < d_end; d += G, ++g) {
+        // groups whose loads were issued after group g's: min(LA-1, ...) ; stores issued after them: min(g, LA-1) groups
+        int allow = 0;
+        if (exact_stores) allow = min(LA - 1, ngroups - 1 - g) * loads_per_group + min(g, LA) * (G * NPIX);
+        else if (ngroups - 1 - g >= LA - 1 && g == 0) allow = (LA - 1) * loads_per_group;
+        wait_vmcnt_le(allow);
         __builtin_amdgcn_s_barrier();             // everyone's loads landed; everyone is done with the slots reused next
-        if (d + G < d_end) {
-            for (int c = 0; c < G; ++c) {
-                issue_plane(P_next, slot_next);
-                ++P_next;
-                slot_next = (slot_next + 1 == R) ? 0 : slot_next + 1;
-            }
-        }
-        if (first) {
+        if (g + LA < ngroups) issue_planes(G);
+        if (g == 0) {
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const int sl = (slot_cur + c >= R) ? slot_cur + c - R : slot_cur + c;
@@ -630,7 +655,6 @@ __global__ __launch_bounds__(256) void affine_march_zsep(const float* __restrict
                 for (int px = 0; px < NPIX; ++px)
                     carry[px][c] = plane_partial<KIND>(pl + qoff[px], Lx, fy[px], fx[px], wy[px], wx[px]);
             }
-            first = false;
         }
 #pragma unroll
         for (int i = 0; i < G; ++i) {
@@ -638,9 +662,9 @@ __global__ __launch_bounds__(256) void affine_march_zsep(const float* __restrict
             sl = (sl >= R) ? sl - R : sl;
             const float* pl = lds + sl * plane_floats;
             bool z_ok = true;
-            if (!fast) {
+            if (!all_valid) {
                 const double ez = (double)(d + i) + p.m[3];
-                z_ok = (d + i < d_end) && (ez >= p.vlo[0]) && (ez < p.vhi[0]);
+                z_ok = (ez >= p.vlo[0]) && (ez < p.vhi[0]);
             }
 #pragma unroll
             for (int px = 0; px < NPIX; ++px) {
@@ -656,9 +680,10 @@ __global__ __launch_bounds__(256) void affine_march_zsep(const float* __restrict
                     val = fmaf(wz[3], pn, val);
                     carry[px][0] = carry[px][1]; carry[px][1] = carry[px][2]; carry[px][2] = pn;
                 }
-                if (fast) optr[px][0] = val;
+                const bool inside = in_yx[px] && z_ok;
+                if (exact_stores) optr[px][0] = inside ? val : 0.0f;
                 else if (d + i < d_end && h0 + jh0 + px * RP < p.oH && w0 + kw < p.oW) {
-                    if (in_yx[px] && z_ok) optr[px][0] = val;
+                    if (inside) optr[px][0] = val;
                     else if (!keep) optr[px][0] = 0.0f;
                 }
                 optr[px] += ostride;
@@ -786,32 +811,36 @@ static tiled_fn tiled_entry(int cfg, int kind, bool zsep)
 }
 
 typedef void (*march_fn)(const float*, float*, const AffineParams);
-struct MarchCfg { int th, tw, g; };
+struct MarchCfg { int th, tw, g, la; };
 static const MarchCfg kMarch[] = {
-    {16, 32, 4},    // 0: two pixels per thread, 128-byte store segments
-    {8, 32, 4},     // 1: smaller in-plane box
-    {16, 16, 4},    // 2: smallest box for 45-degree rotations
-    {16, 32, 2},    // 3: shallower ring (more workgroups per CU)
+    {16, 32, 2, 3},   // 0: two pixels per thread, 128-byte store segments, 6 planes in flight
+    {16, 32, 2, 2},   // 1: shallower ring
+    {16, 32, 2, 1},   // 2: shallowest ring (large in-plane boxes)
+    {8, 32, 2, 3},    // 3: smaller in-plane tile
+    {16, 32, 4, 2},   // 4: fewer barriers
+    {16, 32, 2, 5},   // 5: deepest pipeline
 };
 int march_config_count() { return (int)(sizeof(kMarch) / sizeof(kMarch[0])); }
-void march_config(int idx, int* th, int* tw, int* g) { *th = kMarch[idx].th; *tw = kMarch[idx].tw; *g = kMarch[idx].g; }
+void march_config(int idx, int* th, int* tw, int* g, int* la) { *th = kMarch[idx].th; *tw = kMarch[idx].tw; *g = kMarch[idx].g; *la = kMarch[idx].la; }
 
-template <int TH, int TW, int G>
+template <int TH, int TW, int G, int LA>
 static march_fn pick_march(int kind)
 {
     switch (kind) {
-        case 0: return affine_march_zsep<0, TH, TW, G>;
-        case 1: return affine_march_zsep<1, TH, TW, G>;
-        default: return affine_march_zsep<2, TH, TW, G>;
+        case 0: return affine_march_zsep<0, TH, TW, G, LA>;
+        case 1: return affine_march_zsep<1, TH, TW, G, LA>;
+        default: return affine_march_zsep<2, TH, TW, G, LA>;
     }
 }
 static march_fn march_entry(int cfg, int kind)
 {
     switch (cfg) {
-        case 0: return pick_march<16, 32, 4>(kind);
-        case 1: return pick_march<8, 32, 4>(kind);
-        case 2: return pick_march<16, 16, 4>(kind);
-        default: return pick_march<16, 32, 2>(kind);
+        case 0: return pick_march<16, 32, 2, 3>(kind);
+        case 1: return pick_march<16, 32, 2, 2>(kind);
+        case 2: return pick_march<16, 32, 2, 1>(kind);
+        case 3: return pick_march<8, 32, 2, 3>(kind);
+        case 4: return pick_march<16, 32, 4, 2>(kind);
+        default: return pick_march<16, 32, 2, 5>(kind);
     }
 }
 
