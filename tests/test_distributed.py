@@ -1,0 +1,139 @@
+"""Slab partition + halo exchange, on CPU ranks over gloo (world_size 2 and 3).  The compute back end is the CPU
+oracle injected through SlabVolume's `engine` hook, so what is verified here is the partition / exchange /
+offset bookkeeping of voltools_amd/distributed.py; the HIP slab kernels are verified in test_gpu_parity.py."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from voltools_amd.distributed import plan_halo_exchange, slab_bounds, stencil_halo, axis0_reach
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_plan_halo_exchange_neighbours_only():
+    counts = [10, 10, 10, 10]
+    (w0, w1), recvs, sends = plan_halo_exchange(counts, 1, 2)
+    assert (w0, w1) == (8, 22)
+    assert sorted(recvs) == [(0, 8, 10), (2, 20, 22)]
+    assert sorted(sends) == [(0, 10, 12), (2, 18, 20)]
+    (w0, w1), recvs, sends = plan_halo_exchange(counts, 0, 2)
+    assert (w0, w1) == (0, 12) and recvs == [(1, 10, 12)] and sends == [(1, 8, 10)]
+
+
+def test_plan_halo_exchange_multi_hop_and_replication():
+    counts = [4, 4, 4]
+    (w0, w1), recvs, sends = plan_halo_exchange(counts, 0, 6)          # halo wider than a slab: two sources
+    assert (w0, w1) == (0, 10) and sorted(recvs) == [(1, 4, 8), (2, 8, 10)]
+    (w0, w1), recvs, sends = plan_halo_exchange(counts, 1, 100)        # replicate everything
+    assert (w0, w1) == (0, 12) and sorted(recvs) == [(0, 0, 4), (2, 8, 12)]
+    # symmetry: what r receives from s is what s sends to r
+    for halo in (1, 3, 7, 50):
+        for r in range(3):
+            _, recvs, _ = plan_halo_exchange([5, 3, 6], r, halo)
+            for s, a, b in recvs:
+                _, _, sends = plan_halo_exchange([5, 3, 6], s, halo)
+                assert (r, a, b) in sends
+
+
+def test_halo_sizes_and_reach():
+    assert stencil_halo('linear') == 1 and stencil_halo('bspline') == 2 and stencil_halo('filt_bspline') == 18
+    assert slab_bounds([3, 4]) == [(0, 3), (3, 7)]
+    import voltools_amd as vt
+    m = vt.utils.transform_matrix(rotation=(0, 33, 0), center=(10, 10, 10))
+    lo, hi = axis0_reach(m, (4, 8), (20, 20))
+    assert (lo, hi) == (4.0, 7.0)                                        # in-plane rotation: no axis-0 reach
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, counts, interp, reach, matrices, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    from oracle import oracle
+    from voltools_amd.distributed import SlabVolume, slab_bounds
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        G, H, W = sum(counts), 18, 22
+        vol = np.random.RandomState(42).random_sample((G, H, W)).astype(np.float32)
+        g0, g1 = slab_bounds(counts)[rank]
+
+        class Engine:
+            def __init__(self, window, plane0, gD, out_plane0, out_depth, interpolation):
+                self.src = window.numpy().copy()
+                if interpolation.startswith('filt_'):
+                    self.src = oracle.prefilter(self.src)
+                self.args = (plane0, gD, out_plane0, out_depth, interpolation)
+
+            def affine(self, m, output):
+                plane0, gD, out_plane0, out_depth, interpolation = self.args
+                return oracle.affine_ex(self.src, np.asarray(m, np.float64), interpolation, (out_depth, H, W),
+                                        plane0=plane0, global_depth=gD, out_plane0=out_plane0)
+
+        sv = SlabVolume(vol[g0:g1], interpolation=interp, device='cpu', reach=reach, engine=Engine)
+        assert sv.global_shape == (G, H, W) and sv.shape == (g1 - g0, H, W)
+        for i, m in enumerate(matrices):
+            try:
+                out = sv.affine(m)
+                np.save(os.path.join(outdir, f'out_{i}_{rank}.npy'), out)
+            except ValueError as e:
+                open(os.path.join(outdir, f'err_{i}_{rank}.txt'), 'w').write(str(e))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world, counts, interp, reach, matrices, tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, counts, interp, reach, matrices, str(tmp_path)), nprocs=world, join=True)
+
+
+@pytest.mark.parametrize('world,counts', [(2, [12, 12]), (3, [9, 7, 8])])
+@pytest.mark.parametrize('interp', ['linear', 'bspline', 'filt_bspline'])
+def test_slab_volume_matches_single_volume(world, counts, interp, tmp_path):
+    import voltools_amd as vt
+    from oracle import oracle
+    G, H, W = sum(counts), 18, 22
+    vol = np.random.RandomState(42).random_sample((G, H, W)).astype(np.float32)
+    c = np.divide(np.subtract((G, H, W), 1), 2, dtype=np.float32)
+    matrices = [vt.utils.transform_matrix(rotation=(0, 33, 0), center=c),                       # README sweep family
+                vt.utils.transform_matrix(rotation=(0, 45, 0), translation=(0, 1.5, -2), center=c),
+                np.eye(4, dtype=np.float32)]
+    _run(world, counts, interp, 0, matrices, tmp_path)
+    tol = 2e-6 if not interp.startswith('filt') else 2e-5
+    for i, m in enumerate(matrices):
+        got = np.concatenate([np.load(tmp_path / f'out_{i}_{r}.npy') for r in range(world)])
+        want = oracle.affine(vol, m, interp)
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= tol, (interp, i)
+
+
+def test_general_rotation_needs_reach_and_replication_works(tmp_path):
+    import voltools_amd as vt
+    from oracle import oracle
+    counts = [12, 12]
+    G, H, W = 24, 18, 22
+    vol = np.random.RandomState(42).random_sample((G, H, W)).astype(np.float32)
+    c = np.divide(np.subtract((G, H, W), 1), 2, dtype=np.float32)
+    m = vt.utils.transform_matrix(rotation=(25, -40, 70), rotation_order='sxyz', center=c)
+    # reach 0: refused loudly on every rank
+    _run(2, counts, 'linear', 0, [m], tmp_path)
+    assert all((tmp_path / f'err_0_{r}.txt').exists() for r in range(2))
+    for f in tmp_path.iterdir():
+        f.unlink()
+    # reach >= G: the source is replicated, results match the single-volume transform
+    _run(2, counts, 'linear', G, [m], tmp_path)
+    got = np.concatenate([np.load(tmp_path / f'out_0_{r}.npy') for r in range(2)])
+    assert np.abs(got - oracle.affine(vol, m, 'linear')).max() <= 2e-6

@@ -295,3 +295,66 @@ def test_full_size_properties_512(interp):
     assert np.abs(a - out.get()).max() <= tol
     sv.close()
     out.free()
+
+
+@pytest.mark.parametrize('interp', ['linear', 'bspline', 'filt_bspline'])
+def test_slab_handles_reproduce_whole_volume(interp):
+    """vt_volume_create_slab: resident windows with halo planes + output-plane offsets (the multi-GPU building block),
+    all slabs on one GPU here."""
+    import ctypes
+    from voltools_amd.distributed import plan_halo_exchange, slab_bounds, stencil_halo
+    lib = _native.load()
+    counts = [30, 36, 30]
+    G, H, W = sum(counts), 40, 46
+    vol = rand_vol((G, H, W), 11)
+    c = centre((G, H, W))
+    mats = [vt.utils.transform_matrix(rotation=(0, 33, 0), translation=(0.0, 1.5, -2.0), center=c),
+            vt.utils.transform_matrix(rotation=(0, 45, 0), translation=(1.25, 0, 0), center=c)]
+    halo = stencil_halo(interp) + 2
+    tol = TOL[interp] if not interp.startswith('filt') else 2e-5
+    for m in mats:
+        want = oracle.affine(vol, m, interp)
+        for flags in (0, _native.NO_MARCH, _native.NO_ZSEP, _native.FORCE_DIRECT):
+            parts = []
+            for r, (g0, g1) in enumerate(slab_bounds(counts)):
+                (w0, w1), _, _ = plan_halo_exchange(counts, r, halo)
+                win = np.ascontiguousarray(vol[w0:w1])
+                cflags = (_native.SLAB_LO_INTERIOR if w0 > 0 else 0) | (_native.SLAB_HI_INTERIOR if w1 < G else 0)
+                h = ctypes.c_void_p()
+                _native.check(lib.vt_volume_create_slab(0, w1 - w0, H, W, _native.INTERP_CODES[interp], win.ctypes.data,
+                                                        cflags, w0, G, g0, g1 - g0, ctypes.byref(h)), 'vt_volume_create_slab')
+                out = np.empty((g1 - g0, H, W), np.float32)
+                m32 = np.ascontiguousarray(m, dtype=np.float32)
+                _native.check(lib.vt_volume_affine(h, m32.ctypes.data, out.ctypes.data, flags | _native.FORCE_TILED * (flags != _native.FORCE_DIRECT)),
+                              'vt_volume_affine')
+                lib.vt_volume_destroy(h)
+                parts.append(out)
+            got = np.concatenate(parts)
+            assert np.abs(got - want).max() <= tol, (interp, flags)
+
+
+def test_slab_volume_single_rank_process_group():
+    """The product multi-GPU class end to end on one rank (RCCL process group of size 1)."""
+    torch = pytest.importorskip('torch')
+    import torch.distributed as dist
+    from voltools_amd.distributed import SlabVolume
+    import os
+    import socket
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        shape = (64, 48, 52)
+        vol = rand_vol(shape, 12)
+        sv = SlabVolume(vol, interpolation='filt_bspline', device='gpu:0')
+        m = vt.utils.transform_matrix(rotation=(0, 45, 0), center=centre(shape))
+        out = vt.empty(shape, device='gpu:0')
+        assert sv.affine(m, output=out) is None
+        sv.synchronize()
+        assert np.abs(out.get() - oracle.affine(vol, m, 'filt_bspline')).max() <= 1e-5
+        with pytest.raises(ValueError):
+            SlabVolume(vol, interpolation='linear', device='gpu:0').affine(np.eye(4, dtype=np.float32)[[1, 0, 2, 3]])
+        sv.close()
+    finally:
+        dist.destroy_process_group()
