@@ -36,25 +36,28 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(vol, interp, matrix, target_s):
+def cpu_baseline(vol, interp, matrices, target_s):
     """The CPU oracle (a port of the reference GPU-path semantics, OpenMP) timed on a bounded sample of the
-    same workload: a block of output planes of the same 512^3 transform.  Reported, never the target."""
+    same workload: blocks of output planes of the same 512^3 sweep.  Reported, never the target."""
     from oracle import oracle
     threads = oracle.num_threads()
     n = vol.shape[0]
     src = oracle.prefilter(vol) if interp.startswith('filt') else vol
-    m64 = np.asarray(matrix, dtype=np.float64)
-    planes, mid = 2, n // 2
-    t0 = time.perf_counter()
-    oracle.affine_ex(src, m64, interp, (planes, n, n), out_plane0=mid)
-    dt = time.perf_counter() - t0
-    planes = int(max(2, min(n // 2, planes * target_s / max(dt, 1e-3))))
-    t0 = time.perf_counter()
-    oracle.affine_ex(src, m64, interp, (planes, n, n), out_plane0=mid - planes // 2)
-    dt = time.perf_counter() - t0
-    res = {'value': round(planes * n * n / dt / 1e6, 2), 'unit': 'Mvoxels/s', 'cores': threads, 'kind': 'port',
-           'sample': f'{planes} of {n} output planes of the same {n}^3 {interp} transform (prefilter not timed), '
-                     f'oracle/vt_oracle.c with {threads} OpenMP threads, {dt:.1f} s'}
+    planes = n // 2
+    done, dt, k = 0, 0.0, 0
+    t_begin = time.perf_counter()
+    while dt < target_s and k < len(matrices):
+        m64 = np.asarray(matrices[k], dtype=np.float64)
+        t0 = time.perf_counter()
+        oracle.affine_ex(src, m64, interp, (planes, n, n), out_plane0=n // 4)
+        dt += time.perf_counter() - t0
+        done += planes * n * n
+        k += 1
+        if time.perf_counter() - t_begin > 3 * target_s:
+            break
+    res = {'value': round(done / dt / 1e6, 2), 'unit': 'Mvoxels/s', 'cores': threads, 'kind': 'port',
+           'sample': f'{k} sweep angles x {planes} of {n} output planes of the same {n}^3 {interp} transform (prefilter not '
+                     f'timed), oracle/vt_oracle.c with {threads} OpenMP threads, {dt:.1f} s of CPU work'}
     # the reference's actual CPU path (scipy, single-threaded) on BASELINE config #1's size
     try:
         import voltools_amd as vt
@@ -62,11 +65,32 @@ def cpu_baseline(vol, interp, matrix, target_s):
         t0 = time.perf_counter()
         vt.transform(small, rotation=(0, 45, 0), interpolation=interp, device='cpu')
         dt = time.perf_counter() - t0
-        res['scipy_1thread'] = {'value': round(200 ** 3 / dt / 1e6, 2), 'unit': 'Mvoxels/s',
-                                'sample': f'200^3 {interp} via voltools_amd device="cpu" (scipy.ndimage.affine_transform), {dt:.1f} s'}
+        res['scipy_1thread'] = {'value': round(200 ** 3 / dt / 1e6, 2), 'unit': 'Mvoxels/s', 'cores': 1,
+                                'sample': f'200^3 {interp} via voltools_amd device="cpu" (scipy.ndimage.affine_transform, the '
+                                          f'reference CPU path), {dt:.1f} s'}
     except Exception as e:  # pragma: no cover
         res['scipy_1thread'] = {'error': str(e)}
     return res
+
+
+def measured_traffic(kernel_prefix):
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (profiles/*_summary.json,
+    produced by tools/profile_bench.sh on this same command), FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_summary.json'))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        tot, cnt = 0.0, 0
+        for name, m in d.get('pmc_mean_per_launch', {}).items():
+            if name.startswith(kernel_prefix) and 'hbm_traffic_bytes' in m:
+                tot += m['hbm_traffic_bytes'] * m.get('launches_sampled', 1)
+                cnt += m.get('launches_sampled', 1)
+        if cnt:
+            best = {'bytes': tot / cnt, 'source': os.path.basename(f)}
+    return best
 
 
 def main():
@@ -128,6 +152,10 @@ def main():
     kernel_ms = kernel_ms_total / args.steps
     algo_bytes = 8.0 * n * n * n                     # 4 B compulsory source read + 4 B store per output voxel
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+    kind_code = {'linear': 0, 'bspline': 1, 'filt_bspline': 1}.get(interp, 2)
+    kname = {1: f'vt::affine_direct<{kind_code}>', 2: f'vt::affine_tiled<{kind_code}', 3: f'vt::affine_tiled_zsep<{kind_code}',
+             4: f'vt::affine_march_zsep<{kind_code}'}.get(int(info.last_kernel), 'vt::affine')
+    traffic = measured_traffic('void ' + kname) if (n == 512 and world == 1) else None
     result = {
         'metric': 'Mvoxels/s, 512^3 f32 filt_bspline StaticVolume transform (resident source, device output)',
         'value': round(value, 1), 'unit': 'Mvoxels/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -137,8 +165,10 @@ def main():
                                f'output= device buffer' + (f', {world} axis-0 slabs of {n}^3' if world > 1 else ''),
                    'tile': list(info.last_tile), 'lds_bytes': int(info.last_lds_bytes), 'kernel': int(info.last_kernel),
                    'prefilter_ms_once': round(float(info.prefilter_ms), 3)},
-        'roofline': {'bound': 'hbm', 'kernel': f'affine_tiled<{interp}>', 'achieved': round(achieved, 1), 'peak': 8000.0,
-                     'unit': 'GB/s', 'frac': round(achieved / 8000.0, 4), 'traffic': None,
+        'roofline': {'bound': 'hbm', 'kernel': kname, 'achieved': round(achieved, 1), 'peak': 8000.0,
+                     'unit': 'GB/s', 'frac': round(achieved / 8000.0, 4),
+                     'traffic': (round(traffic['bytes']) if traffic else None),
+                     'traffic_source': (traffic['source'] if traffic else None),
                      'kernel_ms': round(kernel_ms, 4), 'algorithmic_bytes_per_launch': algo_bytes},
     }
 
@@ -163,7 +193,7 @@ def main():
                                   'algorithmic_bytes': 24.0 * n ** 3}
         result['extra'] = extra
         if not args.no_cpu_baseline:
-            result['cpu_baseline'] = cpu_baseline(vol, interp, mats[args.warmup + 45 % args.steps], args.cpu_seconds)
+            result['cpu_baseline'] = cpu_baseline(vol, interp, mats[args.warmup:], args.cpu_seconds)
 
     sv.close()
     out.free()

@@ -353,8 +353,10 @@ def test_slab_volume_single_rank_process_group():
         assert sv.affine(m, output=out) is None
         sv.synchronize()
         assert np.abs(out.get() - oracle.affine(vol, m, 'filt_bspline')).max() <= 1e-5
-        with pytest.raises(ValueError):
-            SlabVolume(vol, interpolation='linear', device='gpu:0').affine(np.eye(4, dtype=np.float32)[[1, 0, 2, 3]])
+        # a single slab holds the whole volume: any matrix is within reach
+        m = vt.utils.transform_matrix(rotation=(25, -40, 70), rotation_order='sxyz', center=centre(shape))
+        got = sv.affine(m)
+        assert np.abs(got - oracle.affine(vol, m, 'filt_bspline')).max() <= 1e-5
         sv.close()
     finally:
         dist.destroy_process_group()

@@ -107,6 +107,37 @@ int run_prefilter(float* d_a, float* d_b, int D, int H, int W, int P, bool lo_in
     return 0;
 }
 
+// Expected LDS cycles of one half-wave `ds_read2_b32` of the gather (relative to conflict-free = 1.0) when lanes
+// step by (a, b) in (row, column) through an LDS image with row stride Lx: for each of the two dwords, the number
+// of distinct addresses on the busiest of the 32 banks (identical addresses broadcast).  Averaged over a few
+// sub-voxel offsets.  Used to choose the row stride of the marching cubic kernels, which are LDS-bound.
+double gather_conflict_factor(double a, double b, int Lx)
+{
+    double total = 0;
+    int samples = 0;
+    for (int oy = 0; oy < 3; ++oy)
+        for (int ox = 0; ox < 3; ++ox) {
+            const double y0 = 8.0 + 0.37 * oy + 40.0 * std::fabs(std::min(a, 0.0)), x0 = 8.0 + 0.41 * ox + 40.0 * std::fabs(std::min(b, 0.0));
+            for (int dw = 0; dw < 2; ++dw) {
+                int count[32];
+                int addrs[32][32];
+                for (int i = 0; i < 32; ++i) count[i] = 0;
+                for (int l = 0; l < 32; ++l) {
+                    const int addr = (int)std::floor(y0 + a * l) * Lx + (int)std::floor(x0 + b * l) + dw;
+                    const int bank = addr & 31;
+                    bool seen = false;
+                    for (int k = 0; k < count[bank]; ++k) seen = seen || (addrs[bank][k] == addr);
+                    if (!seen) addrs[bank][count[bank]++] = addr;
+                }
+                int worst = 1;
+                for (int i = 0; i < 32; ++i) worst = std::max(worst, count[i]);
+                total += worst;
+                ++samples;
+            }
+        }
+    return total / samples;
+}
+
 // Choose the kernel and tile shape for one matrix (host side, a few hundred flops).
 int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, TilePlan* plan)
 {
@@ -161,6 +192,17 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
             }
             if (!ok) continue;
             L[2] = (L[2] + 3 + 3) & ~3;
+            if (cubic) {
+                // the cubic gather is LDS-bound: pad the row stride (in 16-byte steps) to the value with the fewest
+                // predicted bank conflicts for this matrix' lane step (m[1][2], m[2][2])
+                int best_lx = L[2];
+                double best_f = 1e300;
+                for (int pad = 0; pad <= 28; pad += 4) {
+                    const double f = gather_conflict_factor(m[6], m[10], L[2] + pad) * (1.0 + 0.004 * pad);
+                    if (f < best_f - 1e-9) { best_f = f; best_lx = L[2] + pad; }
+                }
+                L[2] = best_lx;
+            }
             const int ring = (la + 1) * g + halo2 + 1;
             const int64_t bytes = (int64_t)ring * L[1] * L[2] * 4;
             if (L[1] * (L[2] / 4) > 1024 || bytes > v->lds_limit) continue;
