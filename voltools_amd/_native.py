@@ -12,7 +12,7 @@ from typing import Optional, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libvoltools_hip.so')
+LIB_PATH = os.environ.get('VT_LIB') or os.path.join(_HERE, 'lib', 'libvoltools_hip.so')   # VT_LIB: A/B experiments only
 
 INTERP_CODES = {'linear': 0, 'bspline': 1, 'bspline_simple': 2, 'filt_bspline': 3, 'filt_bspline_simple': 4}
 

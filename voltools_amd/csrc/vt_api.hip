@@ -138,6 +138,36 @@ double gather_conflict_factor(double a, double b, int Lx)
     return total / samples;
 }
 
+// Upper estimate of the packed footprint of a TH x TW in-plane tile (16-byte vectors per source plane) under rows 1, 2 of
+// the matrix, as the marching kernel packs it: per source row the tapped span, aligned to 16 bytes.  The tile's sub-voxel
+// position varies from tile to tile, so a 4 x 4 grid of offsets is sampled and a margin added; a tile that still exceeds
+// the slot falls back to a direct gather inside the kernel, so the estimate affects speed only.
+int estimate_packed_vectors(const double m[12], int th, int tw, int halo, int* rows_out)
+{
+    const double a1 = m[5], b1 = m[6], a2 = m[9], b2 = m[10];       // d(sy)/dj, d(sy)/dk, d(sx)/dj, d(sx)/dk
+    double neg1 = 0, neg2 = 0;
+    for (double e : {a1 * (th - 1), b1 * (tw - 1)}) if (e < 0) neg1 += e;
+    for (double e : {a2 * (th - 1), b2 * (tw - 1)}) if (e < 0) neg2 += e;
+    int worst = 0, worst_rows = 0;
+    for (int oy = 0; oy < 4; ++oy)
+        for (int ox = 0; ox < 4; ++ox) {
+            // box-relative base exactly as the kernel forms it: lo = base + neg, o = floor(lo) - halo, b = base - o
+            const double fy0 = 0.25 * oy + 0.013, fx0 = 0.25 * ox + 0.017;
+            const double by = fy0 - neg1 + halo, bx = fx0 - neg2 + halo;   // (+ up to 3 for the 16-byte alignment of o2)
+            int total = 0, rows = 0;
+            for (int Y = 0; Y < 256; ++Y) {
+                int mn, mx;
+                if (!march_row_span(a1, b1, a2, b2, by, bx, Y, th, tw, halo, &mn, &mx)) continue;
+                total += ((mx - mn) >> 2) + 2;                   // +1 vector: unknown 16-byte phase of the span start
+                rows = Y + 1;
+            }
+            worst = std::max(worst, total);
+            worst_rows = std::max(worst_rows, rows);
+        }
+    *rows_out = worst_rows + 1;
+    return worst + worst / 64 + 2;
+}
+
 // Choose the kernel and tile shape for one matrix (host side, a few hundred flops).
 int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, TilePlan* plan)
 {
@@ -154,7 +184,7 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
         if ((step - fl) * 4294967296.0 + 0.5 >= 4294967296.0) { p->inc_lo[r] = 0; p->inc_hi[r] += 1; }
     }
     p->oD = v->oD; p->oH = v->oH; p->oW = v->oW;
-    p->flags = flags & VT_KEEP_OUTSIDE;
+    p->flags = (flags & VT_KEEP_OUTSIDE);
     // skirt rule src + 0.5 in [0, dim) on the global volume, expressed on resident coordinates
     p->vlo[0] = -0.5 - (double)v->plane0;  p->vhi[0] = (double)v->gD - 0.5 - (double)v->plane0;
     p->vlo[1] = -0.5;                      p->vhi[1] = (double)v->H - 0.5;
@@ -177,6 +207,12 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
         // marching kernel: pick the in-plane tile with the least staged bytes per pixel
         const double fl = std::floor(m[3]);
         double best = 1e300;
+        // Footprint staging: the linear kernels stage the packed row spans of the rotated tile (least traffic, least
+        // LDS).  The cubic kernels are LDS-read-bound and sensitive to bank conflicts, which the irregular row starts
+        // of the packed image make worse (measured 0.48 vs 0.39 ms at 45 degrees), so they stage the bounding box with
+        // a conflict-aware row stride.  VT_MARCH_BOX=0/1 overrides.
+        bool march_box = cubic;
+        if (const char* e = std::getenv("VT_MARCH_BOX")) march_box = std::atoi(e) != 0;
         for (int c = 0; c < march_config_count(); ++c) {
             if (v->force_cfg >= 0 && c != v->force_cfg) continue;
             int th, tw, g, la;
@@ -190,11 +226,15 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
                 if (!(ext < 4096.0)) { ok = false; break; }
                 L[r] = (int)std::floor(ext) + 3 + halo2;
             }
-            if (!ok) continue;
-            L[2] = (L[2] + 3 + 3) & ~3;
-            if (cubic) {
-                // the cubic gather is LDS-bound: pad the row stride (in 16-byte steps) to the value with the fewest
-                // predicted bank conflicts for this matrix' lane step (m[1][2], m[2][2])
+            if (!ok || L[1] > march_rows_max()) continue;
+            int rows = 0;
+            const int vecs = estimate_packed_vectors(m, th, tw, cubic ? 1 : 0, &rows);
+            if (vecs > march_vectors_max() || rows > march_rows_max()) continue;
+            int slot_floats = vecs * 4;
+            if (march_box) {
+                // full bounding box with the row stride (in 16-byte steps) that predicts the fewest bank conflicts for
+                // this matrix' lane step (m[1][2], m[2][2])
+                L[2] = (L[2] + 3 + 3) & ~3;
                 int best_lx = L[2];
                 double best_f = 1e300;
                 for (int pad = 0; pad <= 28; pad += 4) {
@@ -202,20 +242,26 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
                     if (f < best_f - 1e-9) { best_f = f; best_lx = L[2] + pad; }
                 }
                 L[2] = best_lx;
+                slot_floats = L[1] * L[2];
+                if (L[1] * L[2] / 4 > march_vectors_max()) continue;
             }
             const int ring = (la + 1) * g + halo2 + 1;
-            const int64_t bytes = (int64_t)ring * L[1] * L[2] * 4;
-            if (L[1] * (L[2] / 4) > 1024 || bytes > v->lds_limit) continue;
+            const int64_t bytes = std::max<int64_t>((int64_t)ring * slot_floats * 4, 1024);
+            if (bytes > v->lds_limit) continue;
             const int blocks_per_cu = (int)std::min<int64_t>(8, (160 * 1024) / bytes);
             // measured on MI355X (512^3 and 1024^3, 0..45 degrees): resident workgroups per CU matter more than
             // lookahead depth inside one workgroup, so rank by occupancy first, then by staged bytes per pixel
-            const double occ = (double)std::min(blocks_per_cu, 8);
-            double cost = (double)(L[1] * L[2]) / (th * tw) * (8.0 / occ) - 1e-3 * la;
+            // and (measured) a deeper ring or a smaller tile never paid off: configurations are listed in order of
+            // preference and the first that fits wins unless VT_TILE forces one
+            (void)blocks_per_cu;
+            double cost = (double)c;
             if (cost < best) {
                 best = cost;
                 plan->kind = 4; plan->cfg = c; plan->td = g; plan->th = th; plan->tw = tw;
                 plan->lds_bytes = (int)bytes;
-                p->Lz = ring; p->Ly = L[1]; p->Lx = L[2];
+                p->Lz = ring; p->Ly = std::min(L[1], march_rows_max()); p->Lx = L[2];
+                p->slot_floats = slot_floats;
+                p->flags = (flags & VT_KEEP_OUTSIDE) | (march_box ? (1 << 20) : 0);
             }
         }
         if (plan->kind == 4) {
@@ -237,12 +283,14 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
             // short chunks keep the workgroups that share source rows (in-plane neighbours) at nearby planes, so the
             // overlap of their boxes is served by the XCD's L2 instead of the fabric (measured: 1024^3 linear
             // 3.4 ms at 342 planes per chunk, 2.1 ms at 16); the cubic kernels pay 5 planes of prologue per chunk
-            const int target_dch = cubic ? 32 : 16;
+            // [measured, 0 and 45 degrees] linear (packed spans): 16 planes at both 512^3 and 1024^3; cubic (boxes): 64 planes
+            // at 512^3 (0.379 vs 0.387 ms), 32 at 1024^3 (2.80 vs 2.88 ms)
+            const int target_dch = cubic ? (((int64_t)v->H * v->W <= 512 * 512) ? 64 : 32) : 16;
             int64_t nchunks = std::max<int64_t>(1, (v->oD + target_dch - 1) / target_dch);
             // the chunk's planes are addressed with a 31-bit scalar byte offset from its first plane
             const int64_t plane_bytes = (int64_t)v->H * v->P * 4;
             nchunks = std::max<int64_t>(nchunks, ((int64_t)v->oD * plane_bytes) / 0x60000000LL + 1);
-            if (const char* e = std::getenv("VT_DCH")) nchunks = std::max<int64_t>(nchunks, (v->oD + std::atoi(e) - 1) / std::max(1, std::atoi(e)));
+            if (const char* e = std::getenv("VT_DCH")) nchunks = std::max<int64_t>(1, (v->oD + std::atoi(e) - 1) / std::max(1, std::atoi(e)));
             int dch = (int)((v->oD + nchunks - 1) / nchunks);
             dch = ((dch + g - 1) / g) * g;
             nchunks = (v->oD + dch - 1) / dch;

@@ -1,0 +1,108 @@
+// vt_device.h -- device helpers shared by the transform kernels (gfx950).
+#pragma once
+#include "vt_internal.h"
+
+namespace vt {
+
+// ---------------------------------------------------------------------------------------------------
+// weights
+// ---------------------------------------------------------------------------------------------------
+
+// bspline.h:102-112
+__device__ __forceinline__ void bspline_weights(float f, float& w0, float& w1, float& w2, float& w3)
+{
+    const float one_frac = 1.0f - f;
+    const float squared = f * f;
+    const float one_sqd = one_frac * one_frac;
+    w0 = (1.0f / 6.0f) * one_sqd * one_frac;
+    w1 = (2.0f / 3.0f) - 0.5f * squared * (2.0f - f);
+    w2 = (2.0f / 3.0f) - 0.5f * one_sqd * (2.0f - one_frac);
+    w3 = (1.0f / 6.0f) * squared * f;
+}
+
+// bspline.h:114-122, evaluated at the four tap offsets -1,0,1,2 of cubicTex3DSimple
+// (helper_interpolation.h:51-61): t = |offset - f| lands in the [1,2), [0,1), (0,1], (1,2] branches.
+__device__ __forceinline__ float bspline_fn(float t)
+{
+    t = fabsf(t);
+    const float a = 2.0f - t;
+    return (t < 1.0f) ? ((2.0f / 3.0f) - 0.5f * t * t * a) : ((t < 2.0f) ? (a * a * a * (1.0f / 6.0f)) : 0.0f);
+}
+
+template <bool SIMPLE>
+__device__ __forceinline__ void cubic_weights(float f, float (&w)[4])
+{
+    if constexpr (SIMPLE) {
+        w[0] = bspline_fn(-1.0f - f);
+        w[1] = bspline_fn(0.0f - f);
+        w[2] = bspline_fn(1.0f - f);
+        w[3] = bspline_fn(2.0f - f);
+    } else {
+        bspline_weights(f, w[0], w[1], w[2], w[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// tiled kernel
+// ---------------------------------------------------------------------------------------------------
+
+// Blocks b and b+8 share an XCD (round-robin dispatch).  Map the blocks of one XCD onto a contiguous
+// range of tile ids (bijective for any grid size).  Placement only affects speed, never results.
+__device__ __forceinline__ int xcd_contiguous(int b, int n)
+{
+    const int xcd = b & 7, q = n >> 3, r = n & 7;
+    const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + (b >> 3);
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// direct (untiled) sampling from global memory with explicit border tests
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fetch0(const float* __restrict__ src, const AffineParams& p, int z, int y, int x)
+{
+    if ((unsigned)z < (unsigned)p.sD && (unsigned)y < (unsigned)p.sH && (unsigned)x < (unsigned)p.sW)
+        return src[((int64_t)z * p.sH + y) * p.sP + x];
+    return 0.0f;
+}
+
+
+// One output value at integer tap origin (iz,iy,ix) and fractions (fz,fy,fx), taps fetched from global memory.
+template <int KIND>
+__device__ __forceinline__ float direct_sample(const float* __restrict__ src, const AffineParams& p,
+                                               int iz, int iy, int ix, float fz, float fy, float fx)
+{
+    if constexpr (KIND == 0) {
+        const float a000 = fetch0(src, p, iz, iy, ix), a001 = fetch0(src, p, iz, iy, ix + 1);
+        const float a010 = fetch0(src, p, iz, iy + 1, ix), a011 = fetch0(src, p, iz, iy + 1, ix + 1);
+        const float a100 = fetch0(src, p, iz + 1, iy, ix), a101 = fetch0(src, p, iz + 1, iy, ix + 1);
+        const float a110 = fetch0(src, p, iz + 1, iy + 1, ix), a111 = fetch0(src, p, iz + 1, iy + 1, ix + 1);
+        const float x00 = fmaf(fx, a001 - a000, a000);
+        const float x01 = fmaf(fx, a011 - a010, a010);
+        const float x10 = fmaf(fx, a101 - a100, a100);
+        const float x11 = fmaf(fx, a111 - a110, a110);
+        const float y0 = fmaf(fy, x01 - x00, x00);
+        const float y1 = fmaf(fy, x11 - x10, x10);
+        return fmaf(fz, y1 - y0, y0);
+    } else {
+        float wx[4], wy[4], wz[4];
+        cubic_weights<KIND == 2>(fx, wx);
+        cubic_weights<KIND == 2>(fy, wy);
+        cubic_weights<KIND == 2>(fz, wz);
+        float val = 0.f;
+        for (int c = 0; c < 4; ++c) {
+            float accy = 0.f;
+            for (int bb = 0; bb < 4; ++bb) {
+                float accx = wx[0] * fetch0(src, p, iz - 1 + c, iy - 1 + bb, ix - 1);
+                accx = fmaf(wx[1], fetch0(src, p, iz - 1 + c, iy - 1 + bb, ix), accx);
+                accx = fmaf(wx[2], fetch0(src, p, iz - 1 + c, iy - 1 + bb, ix + 1), accx);
+                accx = fmaf(wx[3], fetch0(src, p, iz - 1 + c, iy - 1 + bb, ix + 2), accx);
+                accy = fmaf(wy[bb], accx, accy);
+            }
+            val = fmaf(wz[c], accy, val);
+        }
+        return val;
+    }
+}
+
+}  // namespace vt

@@ -1,6 +1,7 @@
 // vt_internal.h -- shared declarations of the HIP library (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 #include "../../include/voltools_hip.h"
 
@@ -32,6 +33,7 @@ struct AffineParams {
     float fz;
     int32_t dch;               // marching kernel: output planes per workgroup
     int32_t zero_off;          // byte offset, inside any source plane, of a 16-byte vector of zeros (row pad)
+    int32_t slot_floats;       // marching kernel: floats per LDS plane slot (packed footprint, multiple of 4)
 };
 
 struct TilePlan {
@@ -42,6 +44,58 @@ struct TilePlan {
     int grid;
 };
 
+// Columns [*mn, *mx] (box-relative) that the pixels of a TH x TW in-plane tile tap in box row Y, for the in-plane map
+// sy = by + a1*j + b1*k, sx = bx + a2*j + b2*k.  A pixel taps the row iff sy lies in [Y-1-halo, Y+halo+1); over the
+// continuous pixel rectangle that is a convex polygon and the extreme sx over it is attained at a vertex: a rectangle
+// corner inside the strip, or a point where a strip line crosses a rectangle edge.  The result is a superset of the
+// taps of the discrete pixels (widened by 1e-6).  Shared by the marching kernel (per workgroup) and the host planner
+// (slot sizing), so both see the same spans.  Returns false when no pixel taps the row.
+__host__ __device__ inline bool march_row_span(double a1, double b1, double a2, double b2, double by, double bx,
+                                               int Y, int TH, int TW, int halo, int* mn, int* mx)
+{
+    const double ylo = (double)(Y - 1 - halo), yhi = (double)(Y + halo + 1);
+    const double jm = (double)(TH - 1), km = (double)(TW - 1);
+    double smin = 1e30, smax = -1e30;
+    for (int cj = 0; cj < 2; ++cj)
+        for (int ck = 0; ck < 2; ++ck) {
+            const double j = cj ? jm : 0.0, k = ck ? km : 0.0;
+            const double sy = by + a1 * j + b1 * k;
+            if (sy >= ylo - 1e-6 && sy <= yhi + 1e-6) {
+                const double sx = bx + a2 * j + b2 * k;
+                smin = sx < smin ? sx : smin;
+                smax = sx > smax ? sx : smax;
+            }
+        }
+    const double ia1 = (a1 > 1e-12 || a1 < -1e-12) ? 1.0 / a1 : 0.0, ib1 = (b1 > 1e-12 || b1 < -1e-12) ? 1.0 / b1 : 0.0;
+    for (int e = 0; e < 2; ++e) {
+        const double L = e ? yhi : ylo;
+        for (int c = 0; c < 2; ++c) {
+            if (ib1 != 0.0) {                 // edges j = 0 and j = TH-1: solve for k
+                const double j = c ? jm : 0.0;
+                const double k = (L - by - a1 * j) * ib1;
+                if (k >= 0.0 && k <= km) {
+                    const double sx = bx + a2 * j + b2 * k;
+                    smin = sx < smin ? sx : smin;
+                    smax = sx > smax ? sx : smax;
+                }
+            }
+            if (ia1 != 0.0) {                 // edges k = 0 and k = TW-1: solve for j
+                const double k = c ? km : 0.0;
+                const double j = (L - by - b1 * k) * ia1;
+                if (j >= 0.0 && j <= jm) {
+                    const double sx = bx + a2 * j + b2 * k;
+                    smin = sx < smin ? sx : smin;
+                    smax = sx > smax ? sx : smax;
+                }
+            }
+        }
+    }
+    if (!(smin <= smax)) { *mn = 0; *mx = -1; return false; }
+    *mn = (int)floor(smin - 1e-6) - halo;
+    *mx = (int)floor(smax + 1e-6) + 1 + halo;
+    return true;
+}
+
 // launchers (vt_kernels_affine.hip)
 int tile_config_count();
 void tile_config(int idx, int* td, int* th, int* tw);
@@ -49,6 +103,10 @@ hipError_t launch_affine_tiled(int cfg, int interp, bool zsep, const float* src,
                                const AffineParams& p, int grid, int lds_bytes, hipStream_t stream);
 int march_config_count();
 void march_config(int idx, int* th, int* tw, int* g, int* la);
+int march_rows_max();
+int march_vectors_max();
+int interp_kind(int interp);
+hipError_t init_march_kernels();
 hipError_t launch_affine_march(int cfg, int interp, const float* src, float* out, const AffineParams& p,
                                int grid, int lds_bytes, hipStream_t stream);
 hipError_t launch_affine_direct(int interp, const float* src, float* out, const AffineParams& p,

@@ -23,59 +23,9 @@
 // A second, untiled kernel (`affine_direct`) gathers straight from global memory.  It is used for tiny
 // volumes (launch-latency regime) and for matrices whose footprint does not fit LDS (large minification).
 #include "vt_internal.h"
+#include "vt_device.h"
 
 namespace vt {
-
-// ---------------------------------------------------------------------------------------------------
-// weights
-// ---------------------------------------------------------------------------------------------------
-
-// bspline.h:102-112
-__device__ __forceinline__ void bspline_weights(float f, float& w0, float& w1, float& w2, float& w3)
-{
-    const float one_frac = 1.0f - f;
-    const float squared = f * f;
-    const float one_sqd = one_frac * one_frac;
-    w0 = (1.0f / 6.0f) * one_sqd * one_frac;
-    w1 = (2.0f / 3.0f) - 0.5f * squared * (2.0f - f);
-    w2 = (2.0f / 3.0f) - 0.5f * one_sqd * (2.0f - one_frac);
-    w3 = (1.0f / 6.0f) * squared * f;
-}
-
-// bspline.h:114-122, evaluated at the four tap offsets -1,0,1,2 of cubicTex3DSimple
-// (helper_interpolation.h:51-61): t = |offset - f| lands in the [1,2), [0,1), (0,1], (1,2] branches.
-__device__ __forceinline__ float bspline_fn(float t)
-{
-    t = fabsf(t);
-    const float a = 2.0f - t;
-    return (t < 1.0f) ? ((2.0f / 3.0f) - 0.5f * t * t * a) : ((t < 2.0f) ? (a * a * a * (1.0f / 6.0f)) : 0.0f);
-}
-
-template <bool SIMPLE>
-__device__ __forceinline__ void cubic_weights(float f, float (&w)[4])
-{
-    if constexpr (SIMPLE) {
-        w[0] = bspline_fn(-1.0f - f);
-        w[1] = bspline_fn(0.0f - f);
-        w[2] = bspline_fn(1.0f - f);
-        w[3] = bspline_fn(2.0f - f);
-    } else {
-        bspline_weights(f, w[0], w[1], w[2], w[3]);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// tiled kernel
-// ---------------------------------------------------------------------------------------------------
-
-// Blocks b and b+8 share an XCD (round-robin dispatch).  Map the blocks of one XCD onto a contiguous
-// range of tile ids (bijective for any grid size).  Placement only affects speed, never results.
-__device__ __forceinline__ int xcd_contiguous(int b, int n)
-{
-    const int xcd = b & 7, q = n >> 3, r = n & 7;
-    const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return start + (b >> 3);
-}
 
 // Stage the source box [o, o+L) into LDS with direct-to-LDS loads (no VGPR round trip, every load of the
 // workgroup in flight at once).  The LDS image is lane-linear: 16-byte vector v of the box lands at
@@ -454,261 +404,12 @@ __global__ __launch_bounds__(256) void affine_tiled_zsep(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------
-// axis-0-separable *marching* kernel
-// ---------------------------------------------------------------------------------------------------
-// Same block-form matrices as affine_tiled_zsep, organised as a software pipeline along axis 0.
-// A workgroup owns one TH x TW in-plane output tile and marches through `dch` output planes:
-//   * per-thread set-up happens once: in-plane tap origin, fractions and weights of its NPIX pixels, and
-//     the byte offsets of the 16-byte source vectors it is responsible for staging (the in-plane box of
-//     the tile is the same for every plane);
-//   * source planes stream through a ring of R = 2G + 2*HALO + 1 LDS slots.  While the workgroup computes
-//     a group of G output planes, the `buffer_load ... lds` (direct-to-LDS) loads of the next G source
-//     planes are in flight -- each costs one instruction and no VALU work: offsets are precomputed,
-//     out-of-volume vectors point at a zero vector that the resident layout keeps at the end of every row;
-//   * every source plane's in-plane partial (bilinear blend / 16-tap B-spline sum) is computed exactly once
-//     per pixel and carried in registers across the 2 (4) output planes that use it;
-//   * one s_barrier per G planes; the wait that precedes it is a *counted* vmcnt so the output stores of
-//     the previous group stay in flight.
-// Per output voxel: 4 (linear) / 16 (cubic) LDS reads, ~12 / ~30 VALU instructions, one 4-byte store.
-// wait until at most n of this wave's vector-memory operations are outstanding (n is wave-uniform, the
-// instruction needs an immediate)
-__device__ __forceinline__ void wait_vmcnt_le(int n)
-{
-#define VT_WCASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-    switch (n) {
-        VT_WCASE(0) VT_WCASE(1) VT_WCASE(2) VT_WCASE(3) VT_WCASE(4) VT_WCASE(5) VT_WCASE(6) VT_WCASE(7)
-        VT_WCASE(8) VT_WCASE(9) VT_WCASE(10) VT_WCASE(11) VT_WCASE(12) VT_WCASE(13) VT_WCASE(14) VT_WCASE(15)
-        VT_WCASE(16) VT_WCASE(17) VT_WCASE(18) VT_WCASE(19) VT_WCASE(20) VT_WCASE(21) VT_WCASE(22) VT_WCASE(23)
-        VT_WCASE(24) VT_WCASE(25) VT_WCASE(26) VT_WCASE(27) VT_WCASE(28) VT_WCASE(29) VT_WCASE(30) VT_WCASE(31)
-        VT_WCASE(32) VT_WCASE(33) VT_WCASE(34) VT_WCASE(35) VT_WCASE(36) VT_WCASE(37) VT_WCASE(38) VT_WCASE(39)
-        VT_WCASE(40) VT_WCASE(41) VT_WCASE(42) VT_WCASE(43) VT_WCASE(44) VT_WCASE(45) VT_WCASE(46) VT_WCASE(47)
-        VT_WCASE(48) VT_WCASE(49) VT_WCASE(50) VT_WCASE(51) VT_WCASE(52) VT_WCASE(53) VT_WCASE(54) VT_WCASE(55)
-        default: asm volatile("s_waitcnt vmcnt(56)" ::: "memory"); break;
-    }
-#undef VT_WCASE
-}
-
-template <int KIND, int TH, int TW, int G, int LA>
-__global__ __launch_bounds__(256) void affine_march_zsep(const float* __restrict__ src, float* __restrict__ out,
-                                                          const AffineParams p)
-{
-    static_assert(256 % TW == 0 && TH % (256 / TW) == 0, "tile/thread mapping");
-    constexpr bool CUBIC = KIND != 0;
-    constexpr int HALO = CUBIC ? 1 : 0;
-    constexpr int NC = 2 * HALO + 1;              // carried partials per pixel
-    constexpr int R = (LA + 1) * G + 2 * HALO + 1;   // ring slots: live group + LA groups in flight
-    constexpr int RP = 256 / TW;
-    constexpr int NPIX = TH / RP;
-    constexpr int MAXIT = 4;                      // in-plane box <= 1024 vectors (16 KiB per plane)
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-
-    const int tid = threadIdx.x;
-    const int t = xcd_contiguous(blockIdx.x, gridDim.x);
-    const int tw_i = t % p.nTw;
-    const int t2 = t / p.nTw;
-    const int th_i = t2 % p.nTh;
-    const int chunk = t2 / p.nTh;
-    const int h0 = th_i * TH, w0 = tw_i * TW;
-    const int d_begin = chunk * p.dch;
-    const int d_end = min(d_begin + p.dch, p.oD);
-
-    // in-plane footprint (rows 1, 2; column 0 of the matrix is zero)
-    double base[3], lo[3], hi[3];
-    bool any_valid = true, all_valid = true;
-#pragma unroll
-    for (int r = 1; r < 3; ++r) {
-        base[r] = fma(p.m[4 * r + 1], (double)h0, fma(p.m[4 * r + 2], (double)w0, p.m[4 * r + 3]));
-        lo[r] = base[r] + p.neg[r];
-        hi[r] = base[r] + p.pos[r];
-        any_valid = any_valid && (hi[r] >= p.vlo[r]) && (lo[r] < p.vhi[r]);
-        all_valid = all_valid && (lo[r] >= p.vlo[r]) && (hi[r] < p.vhi[r]);
-    }
-    const double z_lo = (double)d_begin + p.m[3], z_hi = (double)(d_end - 1) + p.m[3];
-    any_valid = any_valid && (z_hi >= p.vlo[0]) && (z_lo < p.vhi[0]);
-    all_valid = all_valid && (z_lo >= p.vlo[0]) && (z_hi < p.vhi[0]);
-    const bool keep = (p.flags & VT_KEEP_OUTSIDE) != 0;
-    // every lane of the workgroup stores exactly one value per pixel and plane -> the number of stores a wave
-    // has in flight is known, and the wait before the barrier can leave them (and later loads) outstanding
-    const bool exact_stores = (h0 + TH <= p.oH) && (w0 + TW <= p.oW) && ((d_end - d_begin) % G == 0) && (all_valid || !keep);
-    const int64_t ostride = (int64_t)p.oH * p.oW;
-    const int kw = tid % TW;
-    const int jh0 = tid / TW;
-
-    if (!any_valid) {
-        if (!keep) {
-#pragma unroll
-            for (int px = 0; px < NPIX; ++px) {
-                const int h = h0 + jh0 + px * RP, w = w0 + kw;
-                if (h < p.oH && w < p.oW) {
-                    float* optr = out + ((int64_t)d_begin * p.oH + h) * p.oW + w;
-                    for (int d = d_begin; d < d_end; ++d, optr += ostride) *optr = 0.0f;
-                }
-            }
-        }
-        return;
-    }
-
-    const int o1 = (int)floor(lo[1]) - HALO;
-    const int o2 = ((int)floor(lo[2]) - HALO) & ~3;
-    const int Lx = p.Lx, Ly = p.Ly;
-    const int nvx = Lx >> 2;
-    const int nvec = Ly * nvx;                    // 16-byte vectors per plane
-    const int plane_floats = Ly * Lx;
-
-    // staging descriptors: byte offset inside a source plane of each vector this thread loads
-    int voff[MAXIT];
-#pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
-        const int v = tid + 256 * it;
-        const int y = v / nvx;
-        const int cx = v - y * nvx;
-        const int gy = o1 + y, gx = o2 + 4 * cx;
-        const bool ok = (unsigned)gy < (unsigned)p.sH && (unsigned)gx < (unsigned)p.sP;
-        voff[it] = ok ? (gy * p.sP + gx) * 4 : p.zero_off;
-    }
-    const int wave_first = __builtin_amdgcn_readfirstlane(tid & ~63);
-    int nit_w = 0;                                // direct-to-LDS loads this wave issues per plane
-#pragma unroll
-    for (int it = 0; it < MAXIT; ++it) nit_w += (wave_first + 256 * it < nvec) ? 1 : 0;
-    const int plane_bytes = p.sH * p.sP * 4;      // < 2^31 (host-checked)
-    // one buffer descriptor for the whole chunk, based at the first resident plane it touches; the plane is
-    // selected with the scalar offset operand
-    const int P_first = d_begin + p.zoff - HALO;
-    const int P_base = max(0, min(P_first, p.sD - 1));
-    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(reinterpret_cast<const char*>(src) + (int64_t)P_base * plane_bytes), 0, 0x7fffffff, 0x00020000);
-
-    auto issue_plane = [&](int P, int slot) {
-        const bool plane_ok = (unsigned)P < (unsigned)p.sD;
-        const int soff = plane_ok ? (P - P_base) * plane_bytes : 0;
-        float* dst = lds + slot * plane_floats + 4 * wave_first;
-#pragma unroll
-        for (int it = 0; it < MAXIT; ++it) {
-            if (wave_first + 256 * it < nvec) {               // wave-uniform
-                const int off = plane_ok ? voff[it] : p.zero_off;
-                if (tid + 256 * it < nvec)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + 1024 * it),
-                                                             16, off, soff, 0, 0);
-            }
-        }
-    };
-
-    // gather descriptors of this thread's pixels
-    int qoff[NPIX];
-    float fy[NPIX], fx[NPIX];
-    float wy[NPIX][4], wx[NPIX][4];
-    bool in_yx[NPIX];
-    float* optr[NPIX];
-    const double by = base[1] - (double)o1, bx = base[2] - (double)o2;
-#pragma unroll
-    for (int px = 0; px < NPIX; ++px) {
-        const int j = jh0 + px * RP;
-        const double sy = fma(p.m[5], (double)j, fma(p.m[6], (double)kw, by));
-        const double sx = fma(p.m[9], (double)j, fma(p.m[10], (double)kw, bx));
-        const double fyd = floor(sy), fxd = floor(sx);
-        fy[px] = (float)(sy - fyd);
-        fx[px] = (float)(sx - fxd);
-        qoff[px] = __mul24((int)fyd - HALO, Lx) + ((int)fxd - HALO);
-        if constexpr (CUBIC) { cubic_weights<KIND == 2>(fy[px], wy[px]); cubic_weights<KIND == 2>(fx[px], wx[px]); }
-        const double ey = sy + (double)o1, ex = sx + (double)o2;
-        in_yx[px] = all_valid || ((ey >= p.vlo[1]) && (ey < p.vhi[1]) && (ex >= p.vlo[2]) && (ex < p.vhi[2]));
-        optr[px] = out + ((int64_t)d_begin * p.oH + (h0 + j)) * p.oW + (w0 + kw);
-    }
-    const float fz = p.fz;
-    float wz[4] = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (CUBIC) cubic_weights<KIND == 2>(fz, wz);
-
-    // ---- pipeline ----
-    // order of a wave's vector-memory operations:  loads(g0 .. g0+LA-1) | [loads(g+LA) stores(g)] for g = g0, g0+1, ...
-    // => when group g is about to be computed, everything issued after loads(g) may stay outstanding:
-    //    (LA-1) groups of loads and, from the second iteration on, LA-1 ... groups of stores.
-    int P_next = P_first;                         // next source plane to stage
-    int slot_next = 0;
-    auto issue_planes = [&](int count) {
-        for (int c = 0; c < count; ++c) {
-            issue_plane(P_next, slot_next);
-            ++P_next;
-            slot_next = (slot_next + 1 == R) ? 0 : slot_next + 1;
-        }
-    };
-    const int ngroups = (d_end - d_begin + G - 1) / G;
-    issue_planes(G + 2 * HALO + 1);               // group 0 (with its halo planes)
-    for (int a = 1; a < LA; ++a) issue_planes(G); // groups 1 .. LA-1
-    const int loads_per_group = G * nit_w;
-    float carry[NPIX][NC];
-    int slot_cur = 0;                             // slot of source plane zs(d) - HALO
-    int g = 0;
-    for (int d = d_begin; d < d_end; d += G, ++g) {
-        // groups whose loads were issued after group g's: min(LA-1, ...) ; stores issued after them: min(g, LA-1) groups
-        int allow = 0;
-        if (exact_stores) allow = min(LA - 1, ngroups - 1 - g) * loads_per_group + min(g, LA) * (G * NPIX);
-        else if (ngroups - 1 - g >= LA - 1 && g == 0) allow = (LA - 1) * loads_per_group;
-        wait_vmcnt_le(allow);
-        __builtin_amdgcn_s_barrier();             // everyone's loads landed; everyone is done with the slots reused next
-        if (g + LA < ngroups) issue_planes(G);
-        if (g == 0) {
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const int sl = (slot_cur + c >= R) ? slot_cur + c - R : slot_cur + c;
-                const float* pl = lds + sl * plane_floats;
-#pragma unroll
-                for (int px = 0; px < NPIX; ++px)
-                    carry[px][c] = plane_partial<KIND>(pl + qoff[px], Lx, fy[px], fx[px], wy[px], wx[px]);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < G; ++i) {
-            int sl = slot_cur + NC + i;
-            sl = (sl >= R) ? sl - R : sl;
-            const float* pl = lds + sl * plane_floats;
-            bool z_ok = true;
-            if (!all_valid) {
-                const double ez = (double)(d + i) + p.m[3];
-                z_ok = (ez >= p.vlo[0]) && (ez < p.vhi[0]);
-            }
-#pragma unroll
-            for (int px = 0; px < NPIX; ++px) {
-                const float pn = plane_partial<KIND>(pl + qoff[px], Lx, fy[px], fx[px], wy[px], wx[px]);
-                float val;
-                if constexpr (!CUBIC) {
-                    val = fmaf(fz, pn - carry[px][0], carry[px][0]);
-                    carry[px][0] = pn;
-                } else {
-                    val = wz[0] * carry[px][0];
-                    val = fmaf(wz[1], carry[px][1], val);
-                    val = fmaf(wz[2], carry[px][2], val);
-                    val = fmaf(wz[3], pn, val);
-                    carry[px][0] = carry[px][1]; carry[px][1] = carry[px][2]; carry[px][2] = pn;
-                }
-                const bool inside = in_yx[px] && z_ok;
-                if (exact_stores) optr[px][0] = inside ? val : 0.0f;
-                else if (d + i < d_end && h0 + jh0 + px * RP < p.oH && w0 + kw < p.oW) {
-                    if (inside) optr[px][0] = val;
-                    else if (!keep) optr[px][0] = 0.0f;
-                }
-                optr[px] += ostride;
-            }
-        }
-        slot_cur += G;
-        slot_cur = (slot_cur >= R) ? slot_cur - R : slot_cur;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
 // direct kernel: one thread per output voxel, taps from global memory with explicit border tests
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float fetch0(const float* __restrict__ src, const AffineParams& p, int z, int y, int x)
-{
-    if ((unsigned)z < (unsigned)p.sD && (unsigned)y < (unsigned)p.sH && (unsigned)x < (unsigned)p.sW)
-        return src[((int64_t)z * p.sH + y) * p.sP + x];
-    return 0.0f;
-}
-
 template <int KIND>
 __global__ __launch_bounds__(256) void affine_direct(const float* __restrict__ src, float* __restrict__ out,
                                                       const AffineParams p)
 {
-    constexpr bool CUBIC = KIND != 0;
     const int64_t n = (int64_t)p.oD * p.oH * p.oW;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n) return;
@@ -731,37 +432,7 @@ __global__ __launch_bounds__(256) void affine_direct(const float* __restrict__ s
     const double fzd = floor(s[0]), fyd = floor(s[1]), fxd = floor(s[2]);
     const int iz = (int)fzd, iy = (int)fyd, ix = (int)fxd;
     const float fz = (float)(s[0] - fzd), fy = (float)(s[1] - fyd), fx = (float)(s[2] - fxd);
-    float val;
-    if constexpr (!CUBIC) {
-        const float a000 = fetch0(src, p, iz, iy, ix), a001 = fetch0(src, p, iz, iy, ix + 1);
-        const float a010 = fetch0(src, p, iz, iy + 1, ix), a011 = fetch0(src, p, iz, iy + 1, ix + 1);
-        const float a100 = fetch0(src, p, iz + 1, iy, ix), a101 = fetch0(src, p, iz + 1, iy, ix + 1);
-        const float a110 = fetch0(src, p, iz + 1, iy + 1, ix), a111 = fetch0(src, p, iz + 1, iy + 1, ix + 1);
-        const float x00 = fmaf(fx, a001 - a000, a000);
-        const float x01 = fmaf(fx, a011 - a010, a010);
-        const float x10 = fmaf(fx, a101 - a100, a100);
-        const float x11 = fmaf(fx, a111 - a110, a110);
-        const float y0 = fmaf(fy, x01 - x00, x00);
-        const float y1 = fmaf(fy, x11 - x10, x10);
-        val = fmaf(fz, y1 - y0, y0);
-    } else {
-        float wx[4], wy[4], wz[4];
-        cubic_weights<KIND == 2>(fx, wx);
-        cubic_weights<KIND == 2>(fy, wy);
-        cubic_weights<KIND == 2>(fz, wz);
-        val = 0.f;
-        for (int c = 0; c < 4; ++c) {
-            float accy = 0.f;
-            for (int bb = 0; bb < 4; ++bb) {
-                float accx = wx[0] * fetch0(src, p, iz - 1 + c, iy - 1 + bb, ix - 1);
-                accx = fmaf(wx[1], fetch0(src, p, iz - 1 + c, iy - 1 + bb, ix), accx);
-                accx = fmaf(wx[2], fetch0(src, p, iz - 1 + c, iy - 1 + bb, ix + 1), accx);
-                accx = fmaf(wx[3], fetch0(src, p, iz - 1 + c, iy - 1 + bb, ix + 2), accx);
-                accy = fmaf(wy[bb], accx, accy);
-            }
-            val = fmaf(wz[c], accy, val);
-        }
-    }
+    const float val = direct_sample<KIND>(src, p, iz, iy, ix, fz, fy, fx);
     out[idx] = val;
 }
 
@@ -810,41 +481,7 @@ static tiled_fn tiled_entry(int cfg, int kind, bool zsep)
     }
 }
 
-typedef void (*march_fn)(const float*, float*, const AffineParams);
-struct MarchCfg { int th, tw, g, la; };
-static const MarchCfg kMarch[] = {
-    {16, 32, 2, 3},   // 0: two pixels per thread, 128-byte store segments, 6 planes in flight
-    {16, 32, 2, 2},   // 1: shallower ring
-    {16, 32, 2, 1},   // 2: shallowest ring (large in-plane boxes)
-    {8, 32, 2, 3},    // 3: smaller in-plane tile
-    {16, 32, 4, 2},   // 4: fewer barriers
-    {16, 32, 2, 5},   // 5: deepest pipeline
-};
-int march_config_count() { return (int)(sizeof(kMarch) / sizeof(kMarch[0])); }
-void march_config(int idx, int* th, int* tw, int* g, int* la) { *th = kMarch[idx].th; *tw = kMarch[idx].tw; *g = kMarch[idx].g; *la = kMarch[idx].la; }
-
-template <int TH, int TW, int G, int LA>
-static march_fn pick_march(int kind)
-{
-    switch (kind) {
-        case 0: return affine_march_zsep<0, TH, TW, G, LA>;
-        case 1: return affine_march_zsep<1, TH, TW, G, LA>;
-        default: return affine_march_zsep<2, TH, TW, G, LA>;
-    }
-}
-static march_fn march_entry(int cfg, int kind)
-{
-    switch (cfg) {
-        case 0: return pick_march<16, 32, 2, 3>(kind);
-        case 1: return pick_march<16, 32, 2, 2>(kind);
-        case 2: return pick_march<16, 32, 2, 1>(kind);
-        case 3: return pick_march<8, 32, 2, 3>(kind);
-        case 4: return pick_march<16, 32, 4, 2>(kind);
-        default: return pick_march<16, 32, 2, 5>(kind);
-    }
-}
-
-static int interp_kind(int interp)
+int interp_kind(int interp)
 {
     switch (interp) {
         case VT_LINEAR: return 0;
@@ -863,21 +500,7 @@ hipError_t init_affine_kernels()
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 if (e != hipSuccess) return e;
             }
-    for (int cfg = 0; cfg < march_config_count(); ++cfg)
-        for (int kind = 0; kind < 3; ++kind) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(march_entry(cfg, kind)),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-        }
-    return hipSuccess;
-}
-
-hipError_t launch_affine_march(int cfg, int interp, const float* src, float* out, const AffineParams& p,
-                               int grid, int lds_bytes, hipStream_t stream)
-{
-    march_fn fn = march_entry(cfg, interp_kind(interp));
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds_bytes, stream, src, out, p);
-    return hipGetLastError();
+    return init_march_kernels();
 }
 
 hipError_t launch_affine_tiled(int cfg, int interp, bool zsep, const float* src, float* out, const float* zeros16,

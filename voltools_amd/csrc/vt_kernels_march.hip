@@ -1,0 +1,443 @@
+// vt_kernels_march.hip -- the axis-0-separable *marching* transform kernel (gfx950).
+//
+// Matrices of the block form  [1 0 0 tz; 0 a b ty; 0 c d tx]  (rotations about axis 0 -- the README sweep
+// `rotate((0, i, 0))` and every BASELINE configuration --, in-plane scale/shear, any translation): the source plane of an
+// output voxel depends only on d, its in-plane position only on (h, w).  The kernel is a software pipeline along axis 0.
+//
+// A workgroup owns one TH x TW in-plane output tile and marches through `dch` output planes.
+//   * Set-up, once per workgroup.  Every thread computes the in-plane tap origin, fractions and weights of its NPIX
+//     pixels.  The union of all taps is the tile's *footprint*: a rotated rectangle.  Instead of staging its axis-aligned
+//     bounding box (2.7x the tile area at 45 degrees), the workgroup records, per source row, the span [xmin, xmax] that is
+//     actually tapped (LDS atomics), aligns each span to 16 bytes, and packs the spans back to back (a 64-entry prefix sum
+//     done by one wave).  Each thread then derives, once, the byte offsets of the 16-byte source vectors it will stage for
+//     every plane, and the LDS offsets of its taps' rows.  Out-of-volume vectors point at the zero vector the resident
+//     layout keeps at the end of every row (= the texture unit's border mode).
+//   * Source planes stream through a ring of R = (LA+1)G + 2*HALO + 1 LDS slots filled by `buffer_load ... lds`
+//     (direct-to-LDS: one instruction, no VGPR round trip, no VALU work).  While G output planes are computed, the loads
+//     of the following LA groups are in flight.
+//   * Every source plane's in-plane partial (bilinear blend / 16-tap B-spline sum) is computed once per pixel and carried
+//     in registers across the 2 (4) output planes that use it; the z fraction is the same for the whole launch.
+//   * One s_barrier per G planes, preceded by a *counted* s_waitcnt vmcnt(N) that leaves later loads and the previous
+//     groups' stores in flight.
+// Per output voxel: 4 (linear) / 16 (cubic) LDS reads, ~12 / ~30 VALU instructions, one 4-byte store.
+// If a tile's packed footprint exceeds the slot size planned on the host (an estimate with margin), that workgroup falls
+// back to gathering its voxels straight from global memory -- slower, never wrong.
+#include "vt_internal.h"
+#include "vt_device.h"
+
+#include <climits>
+
+namespace vt {
+
+// wait until at most n of this wave's vector-memory operations are outstanding (n is wave-uniform; the instruction
+// needs an immediate)
+__device__ __forceinline__ void wait_vmcnt_le(int n)
+{
+#define VT_WCASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (n) {
+        VT_WCASE(0) VT_WCASE(1) VT_WCASE(2) VT_WCASE(3) VT_WCASE(4) VT_WCASE(5) VT_WCASE(6) VT_WCASE(7)
+        VT_WCASE(8) VT_WCASE(9) VT_WCASE(10) VT_WCASE(11) VT_WCASE(12) VT_WCASE(13) VT_WCASE(14) VT_WCASE(15)
+        VT_WCASE(16) VT_WCASE(17) VT_WCASE(18) VT_WCASE(19) VT_WCASE(20) VT_WCASE(21) VT_WCASE(22) VT_WCASE(23)
+        VT_WCASE(24) VT_WCASE(25) VT_WCASE(26) VT_WCASE(27) VT_WCASE(28) VT_WCASE(29) VT_WCASE(30) VT_WCASE(31)
+        VT_WCASE(32) VT_WCASE(33) VT_WCASE(34) VT_WCASE(35) VT_WCASE(36) VT_WCASE(37) VT_WCASE(38) VT_WCASE(39)
+        VT_WCASE(40) VT_WCASE(41) VT_WCASE(42) VT_WCASE(43) VT_WCASE(44) VT_WCASE(45) VT_WCASE(46) VT_WCASE(47)
+        VT_WCASE(48) VT_WCASE(49) VT_WCASE(50) VT_WCASE(51) VT_WCASE(52) VT_WCASE(53) VT_WCASE(54) VT_WCASE(55)
+        default: asm volatile("s_waitcnt vmcnt(56)" ::: "memory"); break;
+    }
+#undef VT_WCASE
+}
+
+// in-plane partial of one source plane for one pixel; q[] = LDS float offsets of the tap rows inside the plane slot
+template <int KIND, int NR>
+__device__ __forceinline__ float plane_partial_rows(const float* __restrict__ pl, const int (&q)[NR], float fy, float fx,
+                                                    const float (&wy)[4], const float (&wx)[4])
+{
+    if constexpr (KIND == 0) {
+        const float* r0 = pl + q[0];
+        const float* r1 = pl + q[1];
+        const float a00 = r0[0], a01 = r0[1], a10 = r1[0], a11 = r1[1];
+        const float x0 = fmaf(fx, a01 - a00, a00);
+        const float x1 = fmaf(fx, a11 - a10, a10);
+        return fmaf(fy, x1 - x0, x0);
+    } else {
+        float accy = 0.f;
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            const float* rowp = pl + q[bb];
+            float accx = wx[0] * rowp[0];
+            accx = fmaf(wx[1], rowp[1], accx);
+            accx = fmaf(wx[2], rowp[2], accx);
+            accx = fmaf(wx[3], rowp[3], accx);
+            accy = fmaf(wy[bb], accx, accy);
+        }
+        return accy;
+    }
+}
+
+constexpr int kRowsMax = 64;      // source rows a tile's footprint may span (host-checked)
+constexpr int kMaxIt = 4;         // packed footprint <= 1024 vectors (16 KiB) per plane (host-checked via slot size)
+
+template <int KIND, int TH, int TW, int G, int LA>
+__global__ __launch_bounds__(256) void affine_march_zsep(const float* __restrict__ src, float* __restrict__ out,
+                                                          const AffineParams p)
+{
+    static_assert(256 % TW == 0 && TH % (256 / TW) == 0, "tile/thread mapping");
+    constexpr bool CUBIC = KIND != 0;
+    constexpr int HALO = CUBIC ? 1 : 0;
+    constexpr int NR = 2 + 2 * HALO;              // tap rows (and columns) per pixel
+    constexpr int NC = 2 * HALO + 1;              // carried partials per pixel
+    constexpr int R = (LA + 1) * G + 2 * HALO + 1;   // ring slots: live group + LA groups in flight
+    constexpr int RP = 256 / TW;
+    constexpr int NPIX = TH / RP;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int t = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int tw_i = t % p.nTw;
+    const int t2 = t / p.nTw;
+    const int th_i = t2 % p.nTh;
+    const int chunk = t2 / p.nTh;
+    const int h0 = th_i * TH, w0 = tw_i * TW;
+    const int d_begin = chunk * p.dch;
+    const int d_end = min(d_begin + p.dch, p.oD);
+
+    // in-plane footprint (rows 1, 2; column 0 of the matrix is zero)
+    double base[3], lo[3], hi[3];
+    bool any_valid = true, all_valid = true;
+#pragma unroll
+    for (int r = 1; r < 3; ++r) {
+        base[r] = fma(p.m[4 * r + 1], (double)h0, fma(p.m[4 * r + 2], (double)w0, p.m[4 * r + 3]));
+        lo[r] = base[r] + p.neg[r];
+        hi[r] = base[r] + p.pos[r];
+        any_valid = any_valid && (hi[r] >= p.vlo[r]) && (lo[r] < p.vhi[r]);
+        all_valid = all_valid && (lo[r] >= p.vlo[r]) && (hi[r] < p.vhi[r]);
+    }
+    const double z_lo = (double)d_begin + p.m[3], z_hi = (double)(d_end - 1) + p.m[3];
+    any_valid = any_valid && (z_hi >= p.vlo[0]) && (z_lo < p.vhi[0]);
+    all_valid = all_valid && (z_lo >= p.vlo[0]) && (z_hi < p.vhi[0]);
+    const bool keep = (p.flags & VT_KEEP_OUTSIDE) != 0;
+    // every lane of the workgroup stores exactly one value per pixel and plane -> the number of stores a wave has in
+    // flight is known, and the wait before the barrier can leave them (and later loads) outstanding
+    const bool exact_stores = (h0 + TH <= p.oH) && (w0 + TW <= p.oW) && ((d_end - d_begin) % G == 0) && (all_valid || !keep);
+    const int64_t ostride = (int64_t)p.oH * p.oW;
+    const int kw = tid % TW;
+    const int jh0 = tid / TW;
+
+    if (!any_valid) {
+        if (!keep) {
+#pragma unroll
+            for (int px = 0; px < NPIX; ++px) {
+                const int h = h0 + jh0 + px * RP, w = w0 + kw;
+                if (h < p.oH && w < p.oW) {
+                    float* optr = out + ((int64_t)d_begin * p.oH + h) * p.oW + w;
+                    for (int d = d_begin; d < d_end; ++d, optr += ostride) *optr = 0.0f;
+                }
+            }
+        }
+        return;
+    }
+
+    const int o1 = (int)floor(lo[1]) - HALO;
+    const int o2 = ((int)floor(lo[2]) - HALO) & ~3;
+    const int Ly = p.Ly;                          // <= kRowsMax
+
+    // ---- per-pixel tap geometry ----
+    int iy[NPIX], ix[NPIX];
+    float fy[NPIX], fx[NPIX];
+    float wy[NPIX][4], wx[NPIX][4];
+    bool in_yx[NPIX];
+    int64_t ooff[NPIX];                           // element offset of the pixel in output plane d_begin
+    const double by = base[1] - (double)o1, bx = base[2] - (double)o2;
+#pragma unroll
+    for (int px = 0; px < NPIX; ++px) {
+        const int j = jh0 + px * RP;
+        const double sy = fma(p.m[5], (double)j, fma(p.m[6], (double)kw, by));
+        const double sx = fma(p.m[9], (double)j, fma(p.m[10], (double)kw, bx));
+        const double fyd = floor(sy), fxd = floor(sx);
+        fy[px] = (float)(sy - fyd);
+        fx[px] = (float)(sx - fxd);
+        iy[px] = (int)fyd;
+        ix[px] = (int)fxd;
+        if constexpr (CUBIC) { cubic_weights<KIND == 2>(fy[px], wy[px]); cubic_weights<KIND == 2>(fx[px], wx[px]); }
+        else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { wy[px][k] = 0.f; wx[px][k] = 0.f; }
+        }
+        const double ey = sy + (double)o1, ex = sx + (double)o2;
+        in_yx[px] = all_valid || ((ey >= p.vlo[1]) && (ey < p.vhi[1]) && (ex >= p.vlo[2]) && (ex < p.vhi[2]));
+        ooff[px] = ((int64_t)d_begin * p.oH + (h0 + j)) * p.oW + (w0 + kw);
+    }
+
+    int voff[kMaxIt];                             // byte offset inside a source plane of each 16-byte vector this thread stages
+    int q[NPIX][NR];                              // float offset of each tap row of each pixel inside a plane slot
+    int nvec;                                     // 16-byte vectors per plane slot
+    const int slot_floats = p.slot_floats;
+    const bool box_mode = (p.flags & (1 << 20)) != 0;
+    if (box_mode) {
+        // ---- bounding box, row stride Lx (chosen on the host for few bank conflicts) ----
+        const int Lx = p.Lx, nvx = Lx >> 2;
+        nvec = Ly * nvx;
+#pragma unroll
+        for (int it = 0; it < kMaxIt; ++it) {
+            const int v = tid + 256 * it;
+            const int y = v / nvx;
+            const int cx = v - y * nvx;
+            const int gy = o1 + y, gx = o2 + 4 * cx;
+            const bool ok = (v < nvec) && (unsigned)gy < (unsigned)p.sH && (unsigned)gx < (unsigned)p.sP;
+            voff[it] = ok ? (gy * p.sP + gx) * 4 : p.zero_off;
+        }
+#pragma unroll
+        for (int px = 0; px < NPIX; ++px)
+#pragma unroll
+            for (int r = 0; r < NR; ++r) q[px][r] = __mul24(iy[px] - HALO + r, Lx) + (ix[px] - HALO);
+    } else {
+        // ---- row spans of the footprint, packed ----
+        // tab[0..63]: per-row xmin -> x0 (aligned span start); tab[64..127]: per-row xmax -> first vector of the row;
+        // tab[128]: total vectors.  The table overlays the ring (not in use yet).
+        int* tab = reinterpret_cast<int*>(lds);
+        if (tid < kRowsMax) {
+            // Row `tid` of the box: which columns do the tile's pixels tap there?  A pixel (j, k) taps the row iff
+            // sy(j,k) lies in [Y-1-HALO, Y+HALO+1); over the continuous pixel rectangle that is a convex polygon, and
+            // the extreme sx over it is attained at a vertex: a rectangle corner inside the strip, or a point where a
+            // strip line crosses a rectangle edge.  (A superset of the taps of the discrete pixels; widened by 1e-6.)
+            int mn, mx;
+            const bool used = (tid < Ly) && march_row_span(p.m[5], p.m[6], p.m[9], p.m[10], by, bx, tid, TH, TW, HALO, &mn, &mx);
+            const int x0 = used ? (mn & ~3) : 0;
+            const int nv = used ? (((mx - x0) >> 2) + 1) : 0;
+            int incl = nv;
+#pragma unroll
+            for (int s2 = 1; s2 < 64; s2 <<= 1) {
+                const int up = __shfl_up(incl, s2);
+                if (lane >= s2) incl += up;
+            }
+            tab[tid] = x0;
+            tab[kRowsMax + tid] = incl - nv;
+            if (tid == kRowsMax - 1) tab[2 * kRowsMax] = incl;
+        }
+        __syncthreads();
+        nvec = tab[2 * kRowsMax];
+#pragma unroll
+        for (int it = 0; it < kMaxIt; ++it) {
+            const int v = tid + 256 * it;
+            int y = 0;
+            if (v < nvec) {
+                int a = 0, b = Ly - 1;                // largest row whose first vector is <= v
+                while (a < b) {
+                    const int mid = (a + b + 1) >> 1;
+                    if (tab[kRowsMax + mid] <= v) a = mid; else b = mid - 1;
+                }
+                y = a;
+            }
+            const int cx = v - tab[kRowsMax + y];
+            const int gy = o1 + y, gx = o2 + tab[y] + 4 * cx;
+            const bool ok = (v < nvec) && (unsigned)gy < (unsigned)p.sH && (unsigned)gx < (unsigned)p.sP;
+            voff[it] = ok ? (gy * p.sP + gx) * 4 : p.zero_off;
+        }
+#pragma unroll
+        for (int px = 0; px < NPIX; ++px) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int row = min(max(iy[px] - HALO + r, 0), kRowsMax - 1);
+                q[px][r] = 4 * tab[kRowsMax + row] + (ix[px] - HALO - tab[row]);
+            }
+        }
+        __syncthreads();                          // the table is dead from here on; the ring may be written
+    }
+
+    if (nvec * 4 > slot_floats || nvec > 256 * kMaxIt) {
+        // The footprint does not fit the slot planned on the host: gather this workgroup's voxels from global memory
+        // (same arithmetic as affine_direct).
+#pragma unroll
+        for (int px = 0; px < NPIX; ++px) {
+            const int h = h0 + jh0 + px * RP, w = w0 + kw;
+            if (h >= p.oH || w >= p.oW) continue;
+            int64_t oo = ooff[px];
+            for (int d = d_begin; d < d_end; ++d, oo += ostride) {
+                const double ez = (double)d + p.m[3];
+                const bool inside = in_yx[px] && (ez >= p.vlo[0]) && (ez < p.vhi[0]);
+                if (inside) out[oo] = direct_sample<KIND>(src, p, d + p.zoff, o1 + iy[px], o2 + ix[px], p.fz, fy[px], fx[px]);
+                else if (!keep) out[oo] = 0.0f;
+            }
+        }
+        return;
+    }
+
+    const int wave_first = __builtin_amdgcn_readfirstlane(tid & ~63);
+    int nit_w = 0;                                // direct-to-LDS loads this wave issues per plane
+#pragma unroll
+    for (int it = 0; it < kMaxIt; ++it) nit_w += (wave_first + 256 * it < nvec) ? 1 : 0;
+    const int plane_bytes = p.sH * p.sP * 4;      // < 2^31 (host-checked)
+    // one buffer descriptor for the whole chunk, based at the first resident plane it touches; the plane is selected with
+    // the scalar offset operand
+    const int P_first = d_begin + p.zoff - HALO;
+    const int P_base = max(0, min(P_first, p.sD - 1));
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(src) + (int64_t)P_base * plane_bytes), 0, 0x7fffffff, 0x00020000);
+
+    auto issue_plane = [&](int P, int slot) {
+        const bool plane_ok = (unsigned)P < (unsigned)p.sD;
+        const int soff = plane_ok ? (P - P_base) * plane_bytes : 0;
+        float* dst = lds + slot * slot_floats + 4 * wave_first;
+#pragma unroll
+        for (int it = 0; it < kMaxIt; ++it) {
+            if (wave_first + 256 * it < nvec) {               // wave-uniform
+                const int off = plane_ok ? voff[it] : p.zero_off;
+                if (tid + 256 * it < nvec)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + 1024 * it),
+                                                             16, off, soff, 0, 0);
+            }
+        }
+    };
+
+    const float fz = p.fz;
+    float wz[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (CUBIC) cubic_weights<KIND == 2>(fz, wz);
+
+    // ---- pipeline ----
+    // order of a wave's vector-memory operations:  loads(g0 .. g0+LA-1) | [loads(g+LA) stores(g)] for g = g0, g0+1, ...
+    // => when group g is about to be computed, everything issued after loads(g) may stay outstanding.
+    int P_next = P_first;                         // next source plane to stage
+    int slot_next = 0;
+    auto issue_planes = [&](int count) {
+        for (int c = 0; c < count; ++c) {
+            issue_plane(P_next, slot_next);
+            ++P_next;
+            slot_next = (slot_next + 1 == R) ? 0 : slot_next + 1;
+        }
+    };
+    const int ngroups = (d_end - d_begin + G - 1) / G;
+    issue_planes(G + 2 * HALO + 1);               // group 0 (with its halo planes)
+    for (int a = 1; a < LA; ++a) issue_planes(G); // groups 1 .. LA-1
+    const int loads_per_group = G * nit_w;
+    float carry[NPIX][NC];
+    int slot_cur = 0;                             // slot of source plane zs(d) - HALO
+    int g = 0;
+    for (int d = d_begin; d < d_end; d += G, ++g) {
+        if constexpr (LA == 1) {
+            // nothing but the previous group's stores was issued after this group's loads
+            if (exact_stores && g > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * NPIX) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            int allow = 0;
+            if (exact_stores) allow = min(LA - 1, ngroups - 1 - g) * loads_per_group + min(g, LA) * (G * NPIX);
+            else if (g == 0) allow = min(LA - 1, ngroups - 1) * loads_per_group;
+            wait_vmcnt_le(allow);
+        }
+        __builtin_amdgcn_s_barrier();             // everyone's loads landed; everyone is done with the slots reused next
+        if (g + LA < ngroups) issue_planes(G);
+        if (g == 0) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int sl = (slot_cur + c >= R) ? slot_cur + c - R : slot_cur + c;
+                const float* pl = lds + sl * slot_floats;
+#pragma unroll
+                for (int px = 0; px < NPIX; ++px)
+                    carry[px][c] = plane_partial_rows<KIND, NR>(pl, q[px], fy[px], fx[px], wy[px], wx[px]);
+            }
+        }
+        const int64_t dofs = (int64_t)(d - d_begin) * ostride;      // wave-uniform
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            int sl = slot_cur + NC + i;
+            sl = (sl >= R) ? sl - R : sl;
+            const float* pl = lds + sl * slot_floats;
+            bool z_ok = true;
+            if (!all_valid) {
+                const double ez = (double)(d + i) + p.m[3];
+                z_ok = (ez >= p.vlo[0]) && (ez < p.vhi[0]);
+            }
+            float val[NPIX];
+#pragma unroll
+            for (int px = 0; px < NPIX; ++px) {
+                const float pn = plane_partial_rows<KIND, NR>(pl, q[px], fy[px], fx[px], wy[px], wx[px]);
+                if constexpr (!CUBIC) {
+                    val[px] = fmaf(fz, pn - carry[px][0], carry[px][0]);
+                    carry[px][0] = pn;
+                } else {
+                    float acc = wz[0] * carry[px][0];
+                    acc = fmaf(wz[1], carry[px][1], acc);
+                    acc = fmaf(wz[2], carry[px][2], acc);
+                    val[px] = fmaf(wz[3], pn, acc);
+                    carry[px][0] = carry[px][1]; carry[px][1] = carry[px][2]; carry[px][2] = pn;
+                }
+            }
+            if (exact_stores) {
+#pragma unroll
+                for (int px = 0; px < NPIX; ++px)
+                    out[ooff[px] + dofs + i * ostride] = (in_yx[px] && z_ok) ? val[px] : 0.0f;
+            } else if (d + i < d_end) {
+#pragma unroll
+                for (int px = 0; px < NPIX; ++px) {
+                    if (h0 + jh0 + px * RP < p.oH && w0 + kw < p.oW) {
+                        if (in_yx[px] && z_ok) out[ooff[px] + dofs + i * ostride] = val[px];
+                        else if (!keep) out[ooff[px] + dofs + i * ostride] = 0.0f;
+                    }
+                }
+            }
+        }
+        slot_cur += G;
+        slot_cur = (slot_cur >= R) ? slot_cur - R : slot_cur;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+typedef void (*march_fn)(const float*, float*, const AffineParams);
+struct MarchCfg { int th, tw, g, la; };
+static const MarchCfg kMarch[] = {
+    // in order of preference (the planner takes the first that fits LDS)
+    {16, 32, 2, 1},   // 0: two pixels per thread, 128-byte store segments, shallow ring (most workgroups per CU)
+    {8, 32, 2, 1},    // 1: one pixel per thread, half the footprint
+    {16, 32, 2, 2},   // 2: deeper ring (experiments: never faster on MI355X)
+    {16, 32, 2, 3},   // 3
+    {16, 32, 4, 1},   // 4: fewer barriers
+    {32, 32, 2, 1},   // 5: four pixels per thread, longer row spans
+};
+int march_config_count() { return (int)(sizeof(kMarch) / sizeof(kMarch[0])); }
+void march_config(int idx, int* th, int* tw, int* g, int* la) { *th = kMarch[idx].th; *tw = kMarch[idx].tw; *g = kMarch[idx].g; *la = kMarch[idx].la; }
+int march_rows_max() { return kRowsMax; }
+int march_vectors_max() { return 256 * kMaxIt; }
+
+template <int TH, int TW, int G, int LA>
+static march_fn pick_march(int kind)
+{
+    switch (kind) {
+        case 0: return affine_march_zsep<0, TH, TW, G, LA>;
+        case 1: return affine_march_zsep<1, TH, TW, G, LA>;
+        default: return affine_march_zsep<2, TH, TW, G, LA>;
+    }
+}
+static march_fn march_entry(int cfg, int kind)
+{
+    switch (cfg) {
+        case 0: return pick_march<16, 32, 2, 1>(kind);
+        case 1: return pick_march<8, 32, 2, 1>(kind);
+        case 2: return pick_march<16, 32, 2, 2>(kind);
+        case 3: return pick_march<16, 32, 2, 3>(kind);
+        case 4: return pick_march<16, 32, 4, 1>(kind);
+        default: return pick_march<32, 32, 2, 1>(kind);
+    }
+}
+
+hipError_t init_march_kernels()
+{
+    for (int cfg = 0; cfg < march_config_count(); ++cfg)
+        for (int kind = 0; kind < 3; ++kind) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(march_entry(cfg, kind)),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+        }
+    return hipSuccess;
+}
+
+hipError_t launch_affine_march(int cfg, int interp, const float* src, float* out, const AffineParams& p,
+                               int grid, int lds_bytes, hipStream_t stream)
+{
+    march_fn fn = march_entry(cfg, interp_kind(interp));
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds_bytes, stream, src, out, p);
+    return hipGetLastError();
+}
+
+}  // namespace vt
