@@ -67,14 +67,15 @@ def test_tiled_and_direct_match_oracle(interp, mname, shape):
     m = MATRICES[mname](shape)
     want = oracle.affine(vol, m, interp)
     kernels = set()
-    for flags in (_native.FORCE_TILED, _native.FORCE_TILED | _native.NO_MARCH, _native.FORCE_TILED | _native.NO_ZSEP,
-                  _native.FORCE_DIRECT):
+    for flags in (_native.FORCE_TILED, _native.FORCE_TILED | _native.NO_ZPAIR, _native.FORCE_TILED | _native.NO_MARCH,
+                  _native.FORCE_TILED | _native.NO_ZSEP, _native.FORCE_DIRECT):
         got, info = run_case(vol, m, interp, flags)
         kernels.add(info.last_kernel)
         err = np.abs(got - want).max()
         assert err <= TOL[interp], f'{interp}/{mname}/{shape} flags={flags} kernel={info.last_kernel} err={err}'
     if mname in ('identity', 'shift_int', 'shift_frac', 'rot_inplane45'):
         assert 3 in kernels and 4 in kernels         # both axis-0-separable kernels were exercised
+        assert (5 in kernels) == (interp != 'linear')   # cubic: the plane-pair marching kernel too
     if mname not in ('minify_big', 'far_outside'):
         assert 2 in kernels and 1 in kernels
 
@@ -88,7 +89,7 @@ def test_default_dispatch_uses_tiled_kernel_on_large_volumes(interp):
     assert info.last_kernel == 2 and info.last_lds_bytes > 0
     m = MATRICES['rot_inplane45'](shape)
     got, info = run_case(vol, m, interp)
-    assert info.last_kernel == 4
+    assert info.last_kernel == (4 if interp == 'linear' else 5)
     assert np.abs(got - oracle.affine(vol, m, interp)).max() <= TOL[interp]
     assert np.abs(got - oracle.affine(vol, m, interp)).max() <= TOL[interp]
 
@@ -100,8 +101,8 @@ def test_degenerate_and_ragged_shapes(shape, interp):
     for mname in ('identity', 'shift_frac', 'rot_general'):
         m = MATRICES[mname](shape)
         want = oracle.affine(vol, m, interp)
-        for flags in (_native.FORCE_TILED, _native.FORCE_TILED | _native.NO_MARCH, _native.FORCE_TILED | _native.NO_ZSEP,
-                      _native.FORCE_DIRECT):
+        for flags in (_native.FORCE_TILED, _native.FORCE_TILED | _native.NO_ZPAIR, _native.FORCE_TILED | _native.NO_MARCH,
+                      _native.FORCE_TILED | _native.NO_ZSEP, _native.FORCE_DIRECT):
             got, _ = run_case(vol, m, interp, flags)
             assert np.abs(got - want).max() <= TOL[interp], (shape, interp, mname, flags)
 
@@ -250,7 +251,7 @@ def test_full_size_properties_512(interp):
     # identity: linear returns the input bit-for-bit; filt_bspline reproduces it in the interior
     sv.affine(np.eye(4, dtype=np.float32), output=out)
     got = out.get()
-    assert sv.info().last_kernel == 4
+    assert sv.info().last_kernel == (4 if interp == 'linear' else 5)
     if interp == 'linear':
         assert np.array_equal(got, vol)
     else:
@@ -266,7 +267,7 @@ def test_full_size_properties_512(interp):
     m = vt.utils.transform_matrix(rotation=(0, 45, 0), center=centre((n, n, n)))
     sv.affine(m, output=out)
     got = out.get()
-    assert sv.info().last_kernel == 4
+    assert sv.info().last_kernel == (4 if interp == 'linear' else 5)
     d0 = 200
     src = vol if interp == 'linear' else None
     if interp == 'linear':
@@ -284,7 +285,10 @@ def test_full_size_properties_512(interp):
     m = vt.utils.transform_matrix(rotation=(0, 33, 0), translation=(0.25, 1.5, -2.0), center=centre((n, n, n)))
     sv.affine(m, output=out)
     a = out.get()
+    assert sv.info().last_kernel == (4 if interp == 'linear' else 5)
+    sv.affine(m, output=out, _flags=_native.NO_ZPAIR)
     assert sv.info().last_kernel == 4
+    assert np.abs(a - out.get()).max() <= tol
     sv.affine(m, output=out, _flags=_native.NO_MARCH)
     assert sv.info().last_kernel == 3
     assert np.abs(a - out.get()).max() <= tol
@@ -314,7 +318,7 @@ def test_slab_handles_reproduce_whole_volume(interp):
     tol = TOL[interp] if not interp.startswith('filt') else 2e-5
     for m in mats:
         want = oracle.affine(vol, m, interp)
-        for flags in (0, _native.NO_MARCH, _native.NO_ZSEP, _native.FORCE_DIRECT):
+        for flags in (0, _native.NO_ZPAIR, _native.NO_MARCH, _native.NO_ZSEP, _native.FORCE_DIRECT):
             parts = []
             for r, (g0, g1) in enumerate(slab_bounds(counts)):
                 (w0, w1), _, _ = plan_halo_exchange(counts, r, halo)

@@ -72,6 +72,8 @@ struct vt_volume {
     int P = 0;                         // row pitch of d_src in floats: W rounded up to 4, pad columns hold 0
     float* d_src = nullptr;
     float* d_zeros = nullptr;          // 16 bytes of zeros: the border fetch target of the tiled kernel
+    float* d_src_zp = nullptr;         // second resident copy, planes interleaved in pairs (cubic marching kernel); lazy
+    int P2 = 0;                        // floats per pair-row of d_src_zp
     float* d_scratch_out = nullptr;    // staging for host outputs
     size_t scratch_elems = 0;
     hipStream_t stream = nullptr;
@@ -111,14 +113,14 @@ int run_prefilter(float* d_a, float* d_b, int D, int H, int W, int P, bool lo_in
 // step by (a, b) in (row, column) through an LDS image with row stride Lx: for each of the two dwords, the number
 // of distinct addresses on the busiest of the 32 banks (identical addresses broadcast).  Averaged over a few
 // sub-voxel offsets.  Used to choose the row stride of the marching cubic kernels, which are LDS-bound.
-double gather_conflict_factor(double a, double b, int Lx)
+double gather_conflict_factor(double a, double b, int Lx, int ndw = 2)
 {
     double total = 0;
     int samples = 0;
     for (int oy = 0; oy < 3; ++oy)
         for (int ox = 0; ox < 3; ++ox) {
             const double y0 = 8.0 + 0.37 * oy + 40.0 * std::fabs(std::min(a, 0.0)), x0 = 8.0 + 0.41 * ox + 40.0 * std::fabs(std::min(b, 0.0));
-            for (int dw = 0; dw < 2; ++dw) {
+            for (int dw = 0; dw < ndw; ++dw) {
                 int count[32];
                 int addrs[32][32];
                 for (int i = 0; i < 32; ++i) count[i] = 0;
@@ -207,6 +209,75 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
         // marching kernel: pick the in-plane tile with the least staged bytes per pixel
         const double fl = std::floor(m[3]);
         double best = 1e300;
+        // cubic: plane-pair layout + ds_read_b64 gather (kind 5)
+        if (cubic && !(flags & VT_NO_ZPAIR) && (int64_t)v->H * (2 * (((v->W + 3) & ~3) + 4)) * 4 < 0x7fffffffLL) {
+            const double fl = std::floor(m[3]);
+            for (int c = 0; c < zpair_config_count() && plan->kind != 5; ++c) {
+                if (v->force_cfg >= 0 && c != v->force_cfg) continue;
+                int th, tw, la;
+                zpair_config(c, &th, &tw, &la);
+                const int T[3] = {1, th, tw};
+                int L[3] = {0, 0, 0};
+                bool ok = true;
+                for (int r = 1; r < 3 && ok; ++r) {
+                    double ext = 0;
+                    for (int k = 1; k < 3; ++k) ext += std::fabs(m[4 * r + k]) * (T[k] - 1);
+                    if (!(ext < 4096.0)) { ok = false; break; }
+                    L[r] = (int)std::floor(ext) + 3 + halo2;
+                }
+                if (!ok) continue;
+                L[2] = (L[2] + 1 + 1) & ~1;                      // origin aligned down by up to 1 position, even width
+                int best_lx = L[2];
+                double best_f = 1e300;
+                for (int pad = 0; pad <= 30; pad += 2) {         // bank-pair index = (y*Lx + x) mod 32 for ds_read_b64
+                    // [measured at 36 and 144 degrees] every 2 positions of padding cost ~3 % (LDS footprint), a
+                    // pathological stride costs 30-50 %: the model flags the pathological ones reliably
+                    const double f = gather_conflict_factor(m[6], m[10], L[2] + pad, 1) * (1.0 + 0.015 * pad);
+                    if (f < best_f - 1e-9) { best_f = f; best_lx = L[2] + pad; }
+                }
+                if (const char* e = std::getenv("VT_LXPAD")) best_lx = L[2] + std::atoi(e);
+                L[2] = best_lx;
+                const int slot_floats = L[1] * L[2] * 2;
+                if (L[1] * (L[2] / 2) > march_vectors_max()) continue;
+                const int64_t bytes = (int64_t)(la + 1) * slot_floats * 4;
+                if (bytes > v->lds_limit) continue;
+                plan->kind = 5; plan->cfg = c; plan->td = 2; plan->th = th; plan->tw = tw;
+                plan->lds_bytes = (int)bytes;
+                p->Lz = la + 1; p->Ly = L[1]; p->Lx = L[2];
+                p->slot_floats = slot_floats;
+            }
+            if (plan->kind == 5) {
+                const int T[3] = {1, plan->th, plan->tw};
+                for (int r = 0; r < 3; ++r) {
+                    double neg = 0, pos = 0;
+                    for (int k = 1; k < 3; ++k) {
+                        const double e = m[4 * r + k] * (T[k] - 1);
+                        if (e < 0) neg += e; else pos += e;
+                    }
+                    p->neg[r] = neg; p->pos[r] = pos;
+                }
+                p->zoff = (int32_t)fl;
+                p->fz = (float)(m[3] - fl);
+                p->nTh = (v->oH + plan->th - 1) / plan->th;
+                p->nTw = (v->oW + plan->tw - 1) / plan->tw;
+                p->sP2 = 2 * (((v->W + 3) & ~3) + 4);
+                p->zero_off2 = 2 * ((v->W + 3) & ~3) * 4;
+                const int64_t inplane = (int64_t)p->nTh * p->nTw;
+                int target_dch = ((int64_t)v->H * v->W <= 512 * 512) ? 64 : 32;
+                if (const char* e = std::getenv("VT_DCH")) target_dch = std::max(2, std::atoi(e));
+                int64_t nchunks = std::max<int64_t>(1, (v->oD + target_dch - 1) / target_dch);
+                const int64_t pair_bytes = (int64_t)v->H * p->sP2 * 4;
+                nchunks = std::max<int64_t>(nchunks, ((int64_t)(v->oD / 2 + 4) * pair_bytes) / 0x60000000LL + 1);
+                int dch = (int)((v->oD + nchunks - 1) / nchunks);
+                dch = (dch + 1) & ~1;
+                nchunks = (v->oD + dch - 1) / dch;
+                p->dch = dch;
+                p->nTd = (int)nchunks;
+                const int64_t grid = inplane * nchunks;
+                if (grid <= 0x7fffffffLL) { plan->grid = (int)grid; return 0; }
+                plan->kind = 1;
+            }
+        }
         // Footprint staging: the linear kernels stage the packed row spans of the rotated tile (least traffic, least
         // LDS).  The cubic kernels are LDS-read-bound and sensitive to bank conflicts, which the irregular row starts
         // of the packed image make worse (measured 0.48 vs 0.39 ms at 45 degrees), so they stage the bounding box with
@@ -238,7 +309,7 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
                 int best_lx = L[2];
                 double best_f = 1e300;
                 for (int pad = 0; pad <= 28; pad += 4) {
-                    const double f = gather_conflict_factor(m[6], m[10], L[2] + pad) * (1.0 + 0.004 * pad);
+                    const double f = gather_conflict_factor(m[6], m[10], L[2] + pad) * (1.0 + 0.015 * pad);
                     if (f < best_f - 1e-9) { best_f = f; best_lx = L[2] + pad; }
                 }
                 L[2] = best_lx;
@@ -391,7 +462,21 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
             VT_HIP(hipMemcpyAsync(d_out, out, n_out * sizeof(float), hipMemcpyHostToDevice, v->stream));
     }
 
-    if (plan.kind == 4) {
+    if (plan.kind == 5) {
+        if (!v->d_src_zp) {
+            // build the plane-pair copy of the (prefiltered) resident source once
+            v->P2 = p.sP2;
+            const size_t zbytes = (size_t)((v->D + 1) / 2) * v->H * v->P2 * sizeof(float);
+            VT_HIP(hipMalloc(reinterpret_cast<void**>(&v->d_src_zp), zbytes));
+            VT_HIP(hipMemsetAsync(v->d_src_zp, 0, zbytes, v->stream));
+            VT_HIP(launch_relayout_zpair(v->d_src, v->d_src_zp, v->D, v->H, v->W, v->P, v->P2, v->stream));
+        }
+        VT_HIP(launch_affine_zpair(plan.cfg, v->interp, v->d_src_zp, d_out, p, plan.grid, plan.lds_bytes, v->stream));
+        v->last_kernel = 5;
+        v->last_tile[0] = plan.td; v->last_tile[1] = plan.th; v->last_tile[2] = plan.tw;
+        v->last_lds[0] = p.Lz; v->last_lds[1] = p.Ly; v->last_lds[2] = p.Lx;
+        v->last_lds_bytes = plan.lds_bytes; v->last_grid = plan.grid;
+    } else if (plan.kind == 4) {
         VT_HIP(launch_affine_march(plan.cfg, v->interp, v->d_src, d_out, p, plan.grid, plan.lds_bytes, v->stream));
         v->last_kernel = 4;
         v->last_tile[0] = plan.td; v->last_tile[1] = plan.th; v->last_tile[2] = plan.tw;
@@ -624,6 +709,7 @@ int vt_volume_destroy(vt_volume_t* v)
     if (v->stream) hipStreamSynchronize(v->stream);
     if (v->d_src) hipFree(v->d_src);
     if (v->d_zeros) hipFree(v->d_zeros);
+    if (v->d_src_zp) hipFree(v->d_src_zp);
     if (v->d_scratch_out) hipFree(v->d_scratch_out);
     if (v->ev0) hipEventDestroy(v->ev0);
     if (v->ev1) hipEventDestroy(v->ev1);
@@ -642,7 +728,8 @@ int vt_volume_info(const vt_volume_t* v, vt_volume_info_t* info)
     for (int i = 0; i < 3; ++i) { info->last_tile[i] = v->last_tile[i]; info->last_lds_dims[i] = v->last_lds[i]; }
     info->last_lds_bytes = v->last_lds_bytes; info->last_grid = v->last_grid;
     info->prefilter_ms = v->prefilter_ms;
-    info->resident_bytes = (uint64_t)v->D * v->H * v->P * sizeof(float);
+    info->resident_bytes = (uint64_t)v->D * v->H * v->P * sizeof(float) +
+                           (v->d_src_zp ? (uint64_t)((v->D + 1) / 2) * v->H * v->P2 * sizeof(float) : 0);
     return 0;
 }
 

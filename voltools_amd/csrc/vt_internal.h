@@ -34,10 +34,12 @@ struct AffineParams {
     int32_t dch;               // marching kernel: output planes per workgroup
     int32_t zero_off;          // byte offset, inside any source plane, of a 16-byte vector of zeros (row pad)
     int32_t slot_floats;       // marching kernel: floats per LDS plane slot (packed footprint, multiple of 4)
+    int32_t sP2;               // plane-pair layout: floats per pair-row (2 * (roundup4(W) + 4))
+    int32_t zero_off2;         // plane-pair layout: byte offset of a zero vector inside any pair-plane
 };
 
 struct TilePlan {
-    int kind;            // 1 direct, 2 tiled, 3 tiled axis-0-separable, 4 marching axis-0-separable
+    int kind;            // 1 direct, 2 tiled, 3 tiled axis-0-separable, 4 marching axis-0-separable, 5 marching on plane pairs
     int cfg;             // index into the tile table
     int td, th, tw;
     int lds_bytes;
@@ -103,6 +105,11 @@ hipError_t launch_affine_tiled(int cfg, int interp, bool zsep, const float* src,
                                const AffineParams& p, int grid, int lds_bytes, hipStream_t stream);
 int march_config_count();
 void march_config(int idx, int* th, int* tw, int* g, int* la);
+int zpair_config_count();
+void zpair_config(int idx, int* th, int* tw, int* la);
+hipError_t launch_affine_zpair(int cfg, int interp, const float* src2, float* out, const AffineParams& p,
+                               int grid, int lds_bytes, hipStream_t stream);
+hipError_t launch_relayout_zpair(const float* src, float* dst, int D, int H, int W, int P, int P2, hipStream_t stream);
 int march_rows_max();
 int march_vectors_max();
 int interp_kind(int interp);

@@ -382,6 +382,242 @@ __global__ __launch_bounds__(256) void affine_march_zsep(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------
+// cubic marching kernel on the plane-pair layout
+// ---------------------------------------------------------------------------------------------------
+// The cubic marching kernel above is bound by LDS reads: 16 dwords per voxel with `ds_read2_b32` (128 B/clk/CU).
+// Here the resident source is a second copy in which planes 2p and 2p+1 are interleaved element by element
+// ([p][y][x][2], built once by relayout_zpair).  One `ds_read_b64` (256 B/clk/CU) then delivers a tap for two source planes,
+// the in-plane 16-tap sums of both planes are formed with packed-f32 FMAs, and the ring shrinks to LA+1 pair slots because
+// every plane's partial is consumed exactly once (the z history lives in registers).
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <int KIND, int TH, int TW, int LA>
+__global__ __launch_bounds__(256) void affine_march_zpair(const float* __restrict__ src2, float* __restrict__ out,
+                                                           const AffineParams p)
+{
+    static_assert(KIND != 0, "cubic only");
+    static_assert(256 % TW == 0 && TH % (256 / TW) == 0, "tile/thread mapping");
+    constexpr int HALO = 1;
+    constexpr int R = LA + 1;                     // ring slots (plane pairs)
+    constexpr int RP = 256 / TW;
+    constexpr int NPIX = TH / RP;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x;
+    const int t = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int tw_i = t % p.nTw;
+    const int t2 = t / p.nTw;
+    const int th_i = t2 % p.nTh;
+    const int chunk = t2 / p.nTh;
+    const int h0 = th_i * TH, w0 = tw_i * TW;
+    const int d_begin = chunk * p.dch;
+    const int d_end = min(d_begin + p.dch, p.oD);
+
+    double base[3], lo[3], hi[3];
+    bool any_valid = true, all_valid = true;
+#pragma unroll
+    for (int r = 1; r < 3; ++r) {
+        base[r] = fma(p.m[4 * r + 1], (double)h0, fma(p.m[4 * r + 2], (double)w0, p.m[4 * r + 3]));
+        lo[r] = base[r] + p.neg[r];
+        hi[r] = base[r] + p.pos[r];
+        any_valid = any_valid && (hi[r] >= p.vlo[r]) && (lo[r] < p.vhi[r]);
+        all_valid = all_valid && (lo[r] >= p.vlo[r]) && (hi[r] < p.vhi[r]);
+    }
+    const double z_lo = (double)d_begin + p.m[3], z_hi = (double)(d_end - 1) + p.m[3];
+    any_valid = any_valid && (z_hi >= p.vlo[0]) && (z_lo < p.vhi[0]);
+    all_valid = all_valid && (z_lo >= p.vlo[0]) && (z_hi < p.vhi[0]);
+    const bool keep = (p.flags & VT_KEEP_OUTSIDE) != 0;
+    const bool exact_stores = (h0 + TH <= p.oH) && (w0 + TW <= p.oW) && (all_valid || !keep);
+    const int64_t ostride = (int64_t)p.oH * p.oW;
+    const int kw = tid % TW;
+    const int jh0 = tid / TW;
+
+    if (!any_valid) {
+        if (!keep) {
+#pragma unroll
+            for (int px = 0; px < NPIX; ++px) {
+                const int h = h0 + jh0 + px * RP, w = w0 + kw;
+                if (h < p.oH && w < p.oW) {
+                    int64_t oo = ((int64_t)d_begin * p.oH + h) * p.oW + w;
+                    for (int d = d_begin; d < d_end; ++d, oo += ostride) out[oo] = 0.0f;
+                }
+            }
+        }
+        return;
+    }
+
+    const int o1 = (int)floor(lo[1]) - HALO;
+    const int o2 = ((int)floor(lo[2]) - HALO) & ~1;            // 16-byte vectors hold 2 positions x 2 planes
+    const int Ly = p.Ly, Lx = p.Lx;                              // Lx in positions, even
+    const int nvx = Lx >> 1;
+    const int nvec = Ly * nvx;
+    const int slot_floats = p.slot_floats;                       // = Ly * Lx * 2
+
+    int voff[kMaxIt];
+#pragma unroll
+    for (int it = 0; it < kMaxIt; ++it) {
+        const int v = tid + 256 * it;
+        const int y = v / nvx;
+        const int cx = v - y * nvx;
+        const int gy = o1 + y, gx = o2 + 2 * cx;
+        const bool ok = (v < nvec) && (unsigned)gy < (unsigned)p.sH && (unsigned)gx < (unsigned)(p.sP2 >> 1);
+        voff[it] = ok ? (gy * p.sP2 + 2 * gx) * 4 : p.zero_off2;
+    }
+
+    int q[NPIX];                                  // float offset of tap (iy-1, ix-1) inside a pair slot
+    float wy[NPIX][4], wx[NPIX][4];
+    bool in_yx[NPIX];
+    int64_t ooff[NPIX];
+    const double by = base[1] - (double)o1, bx = base[2] - (double)o2;
+#pragma unroll
+    for (int px = 0; px < NPIX; ++px) {
+        const int j = jh0 + px * RP;
+        const double sy = fma(p.m[5], (double)j, fma(p.m[6], (double)kw, by));
+        const double sx = fma(p.m[9], (double)j, fma(p.m[10], (double)kw, bx));
+        const double fyd = floor(sy), fxd = floor(sx);
+        cubic_weights<KIND == 2>((float)(sy - fyd), wy[px]);
+        cubic_weights<KIND == 2>((float)(sx - fxd), wx[px]);
+        q[px] = 2 * (__mul24((int)fyd - HALO, Lx) + ((int)fxd - HALO));
+        const double ey = sy + (double)o1, ex = sx + (double)o2;
+        in_yx[px] = all_valid || ((ey >= p.vlo[1]) && (ey < p.vhi[1]) && (ex >= p.vlo[2]) && (ex < p.vhi[2]));
+        ooff[px] = ((int64_t)(h0 + j)) * p.oW + (w0 + kw);
+    }
+    float wz[4];
+    cubic_weights<KIND == 2>(p.fz, wz);
+
+    const int wave_first = __builtin_amdgcn_readfirstlane(tid & ~63);
+    const int pair_bytes = p.sH * p.sP2 * 4;      // < 2^31 (host-checked)
+    const int npairs_res = (p.sD + 1) >> 1;       // resident pairs
+    // first / last source plane any output of the chunk taps, and the pairs holding them
+    const int plane_first = d_begin + p.zoff - HALO, plane_last = d_end - 1 + p.zoff + 2;
+    const int Pp0 = plane_first >> 1, PpN = plane_last >> 1;       // arithmetic shift = floor division
+    const int Pp_base = max(0, min(Pp0, npairs_res - 1));
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(src2) + (int64_t)Pp_base * pair_bytes), 0, 0x7fffffff, 0x00020000);
+
+    auto issue_pair = [&](int Pp, int slot) {
+        const bool pair_ok = (unsigned)Pp < (unsigned)npairs_res;
+        const int soff = pair_ok ? (Pp - Pp_base) * pair_bytes : 0;
+        float* dst = lds + slot * slot_floats + 4 * wave_first;
+#pragma unroll
+        for (int it = 0; it < kMaxIt; ++it) {
+            if (wave_first + 256 * it < nvec) {               // wave-uniform
+                const int off = pair_ok ? voff[it] : p.zero_off2;
+                if (tid + 256 * it < nvec)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + 1024 * it),
+                                                             16, off, soff, 0, 0);
+            }
+        }
+    };
+
+    int Pp_next = Pp0, slot_next = 0;
+    for (int a = 0; a < LA && Pp_next <= PpN; ++a) {
+        issue_pair(Pp_next, slot_next);
+        ++Pp_next;
+        slot_next = (slot_next + 1 == R) ? 0 : slot_next + 1;
+    }
+    float c0[NPIX], c1[NPIX], c2[NPIX];           // in-plane partials of the three previous source planes
+#pragma unroll
+    for (int px = 0; px < NPIX; ++px) { c0[px] = 0.f; c1[px] = 0.f; c2[px] = 0.f; }
+    int slot_cur = 0;
+    int stores_prev = 0;                          // store instructions this wave issued in the previous iteration
+    for (int Pp = Pp0; Pp <= PpN; ++Pp) {
+        // this pair's loads have landed; only the previous iteration's stores were issued after them (LA == 1)
+        if (LA == 1 && exact_stores) {
+            if (stores_prev == 2 * NPIX) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPIX) : "memory");
+            else if (stores_prev == NPIX) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIX) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (Pp_next <= PpN) {
+            issue_pair(Pp_next, slot_next);
+            ++Pp_next;
+            slot_next = (slot_next + 1 == R) ? 0 : slot_next + 1;
+        }
+        const float* pl = lds + slot_cur * slot_floats;
+        v2f part[NPIX];
+#pragma unroll
+        for (int px = 0; px < NPIX; ++px) {
+            v2f accy = {0.f, 0.f};
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                const v2f* rowp = reinterpret_cast<const v2f*>(pl + q[px] + 2 * bb * Lx);
+                v2f accx = rowp[0] * wx[px][0];
+                accx = rowp[1] * wx[px][1] + accx;
+                accx = rowp[2] * wx[px][2] + accx;
+                accx = rowp[3] * wx[px][3] + accx;
+                accy = accx * wy[px][bb] + accy;
+            }
+            part[px] = accy;
+        }
+        stores_prev = 0;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int plane = 2 * Pp + half;      // newest tap plane of output d
+            const int d = plane - 2 - p.zoff;
+            const bool d_ok = (d >= d_begin) && (d < d_end);          // wave-uniform
+            bool z_ok = true;
+            if (!all_valid) {
+                const double ez = (double)d + p.m[3];
+                z_ok = (ez >= p.vlo[0]) && (ez < p.vhi[0]);
+            }
+            float val[NPIX];
+#pragma unroll
+            for (int px = 0; px < NPIX; ++px) {
+                const float pn = half ? part[px].y : part[px].x;
+                float acc = wz[0] * c0[px];
+                acc = fmaf(wz[1], c1[px], acc);
+                acc = fmaf(wz[2], c2[px], acc);
+                val[px] = fmaf(wz[3], pn, acc);
+                c0[px] = c1[px]; c1[px] = c2[px]; c2[px] = pn;
+            }
+            if (d_ok) {
+                const int64_t dofs = (int64_t)d * ostride;
+                if (exact_stores) {
+#pragma unroll
+                    for (int px = 0; px < NPIX; ++px) out[ooff[px] + dofs] = (in_yx[px] && z_ok) ? val[px] : 0.0f;
+                    stores_prev += NPIX;
+                } else {
+#pragma unroll
+                    for (int px = 0; px < NPIX; ++px) {
+                        if (h0 + jh0 + px * RP < p.oH && w0 + kw < p.oW) {
+                            if (in_yx[px] && z_ok) out[ooff[px] + dofs] = val[px];
+                            else if (!keep) out[ooff[px] + dofs] = 0.0f;
+                        }
+                    }
+                }
+            }
+        }
+        slot_cur = (slot_cur + 1 == R) ? 0 : slot_cur + 1;
+    }
+}
+
+// plain [z][y][P] -> pair layout [z/2][y][P2] with element (z, y, x) at 2x + (z & 1); pad columns stay zero
+__global__ __launch_bounds__(256) void relayout_zpair(const float* __restrict__ src, float* __restrict__ dst,
+                                                       int D, int H, int W, int P, int P2)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    const int pp = blockIdx.z;
+    if (x >= W) return;
+    const int z0 = 2 * pp, z1 = z0 + 1;
+    const float a = src[((int64_t)z0 * H + y) * P + x];
+    const float b = (z1 < D) ? src[((int64_t)z1 * H + y) * P + x] : 0.0f;
+    float2* o = reinterpret_cast<float2*>(dst + ((int64_t)pp * H + y) * P2) + x;
+    *o = make_float2(a, b);
+}
+
+hipError_t launch_relayout_zpair(const float* src, float* dst, int D, int H, int W, int P, int P2, hipStream_t stream)
+{
+    const dim3 grid((W + 255) / 256, H, (D + 1) / 2);
+    if (grid.y > 65535 || grid.z > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(relayout_zpair, grid, dim3(256), 0, stream, src, dst, D, H, W, P, P2);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
 typedef void (*march_fn)(const float*, float*, const AffineParams);
@@ -421,8 +657,38 @@ static march_fn march_entry(int cfg, int kind)
     }
 }
 
+typedef void (*zpair_fn)(const float*, float*, const AffineParams);
+static zpair_fn zpair_entry(int cfg, int kind)
+{
+    // cfg 0: 16x32 tile, one pair in flight; cfg 1: 8x32; cfg 2: 16x32, two pairs in flight
+    switch (cfg) {
+        case 0: return kind == 1 ? affine_march_zpair<1, 16, 32, 1> : affine_march_zpair<2, 16, 32, 1>;
+        case 1: return kind == 1 ? affine_march_zpair<1, 8, 32, 1> : affine_march_zpair<2, 8, 32, 1>;
+        default: return kind == 1 ? affine_march_zpair<1, 16, 32, 2> : affine_march_zpair<2, 16, 32, 2>;
+    }
+}
+int zpair_config_count() { return 3; }
+void zpair_config(int idx, int* th, int* tw, int* la)
+{
+    *th = (idx == 1) ? 8 : 16; *tw = 32; *la = (idx == 2) ? 2 : 1;
+}
+
+hipError_t launch_affine_zpair(int cfg, int interp, const float* src2, float* out, const AffineParams& p,
+                               int grid, int lds_bytes, hipStream_t stream)
+{
+    zpair_fn fn = zpair_entry(cfg, interp_kind(interp));
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds_bytes, stream, src2, out, p);
+    return hipGetLastError();
+}
+
 hipError_t init_march_kernels()
 {
+    for (int cfg = 0; cfg < zpair_config_count(); ++cfg)
+        for (int kind = 1; kind < 3; ++kind) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(zpair_entry(cfg, kind)),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+        }
     for (int cfg = 0; cfg < march_config_count(); ++cfg)
         for (int kind = 0; kind < 3; ++kind) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(march_entry(cfg, kind)),
