@@ -537,17 +537,42 @@ __global__ __launch_bounds__(256) void affine_march_zpair(const float* __restric
             slot_next = (slot_next + 1 == R) ? 0 : slot_next + 1;
         }
         const float* pl = lds + slot_cur * slot_floats;
+        // 16 taps x 2 planes per pixel as sixteen ds_read_b64 (2 LDS cycles each).  Written as inline asm because hipcc
+        // fuses adjacent 8-byte LDS loads into ds_read2_b64, which runs at half the bytes per cycle (8 cycles per pair).
         v2f part[NPIX];
+        const unsigned pl_addr = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)pl;
+        v2f tap[NPIX][16];
 #pragma unroll
         for (int px = 0; px < NPIX; ++px) {
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                const unsigned addr = pl_addr + 4u * (unsigned)(q[px] + 2 * bb * Lx);
+                asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %4 offset:16\n\tds_read_b64 %3, %4 offset:24"
+                             : "=&v"(tap[px][4 * bb]), "=&v"(tap[px][4 * bb + 1]), "=&v"(tap[px][4 * bb + 2]), "=&v"(tap[px][4 * bb + 3])
+                             : "v"(addr));
+            }
+        }
+#pragma unroll
+        for (int px = 0; px < NPIX; ++px) {
+            // in-order return: everything but the (NPIX-1-px)*16 youngest reads has landed
+            if (px + 1 < NPIX)
+                asm volatile("s_waitcnt lgkmcnt(%16)"
+                             : "+v"(tap[px][0]), "+v"(tap[px][1]), "+v"(tap[px][2]), "+v"(tap[px][3]), "+v"(tap[px][4]), "+v"(tap[px][5]),
+                               "+v"(tap[px][6]), "+v"(tap[px][7]), "+v"(tap[px][8]), "+v"(tap[px][9]), "+v"(tap[px][10]), "+v"(tap[px][11]),
+                               "+v"(tap[px][12]), "+v"(tap[px][13]), "+v"(tap[px][14]), "+v"(tap[px][15])
+                             : "n"((NPIX - 1 - px) * 16 > 15 ? 15 : (NPIX - 1 - px) * 16));
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(tap[px][0]), "+v"(tap[px][1]), "+v"(tap[px][2]), "+v"(tap[px][3]), "+v"(tap[px][4]), "+v"(tap[px][5]),
+                               "+v"(tap[px][6]), "+v"(tap[px][7]), "+v"(tap[px][8]), "+v"(tap[px][9]), "+v"(tap[px][10]), "+v"(tap[px][11]),
+                               "+v"(tap[px][12]), "+v"(tap[px][13]), "+v"(tap[px][14]), "+v"(tap[px][15]));
             v2f accy = {0.f, 0.f};
 #pragma unroll
             for (int bb = 0; bb < 4; ++bb) {
-                const v2f* rowp = reinterpret_cast<const v2f*>(pl + q[px] + 2 * bb * Lx);
-                v2f accx = rowp[0] * wx[px][0];
-                accx = rowp[1] * wx[px][1] + accx;
-                accx = rowp[2] * wx[px][2] + accx;
-                accx = rowp[3] * wx[px][3] + accx;
+                v2f accx = tap[px][4 * bb] * wx[px][0];
+                accx = tap[px][4 * bb + 1] * wx[px][1] + accx;
+                accx = tap[px][4 * bb + 2] * wx[px][2] + accx;
+                accx = tap[px][4 * bb + 3] * wx[px][3] + accx;
                 accy = accx * wy[px][bb] + accy;
             }
             part[px] = accy;
