@@ -1,4 +1,13 @@
 #!/bin/bash
-python3 tools/angle_sweep.py --interp filt_bspline 2>&1 | grep -v amdgpu
-python3 tools/angle_sweep.py --interp filt_bspline --size 1024 --step 15 2>&1 | grep -v amdgpu
-python bench.py --no-cpu-baseline 2>/dev/null | tail -1
+for tile in 0 1 5; do
+for ang in 0 45 90; do
+  VT_TILE=$tile python3 tools/prof_case.py --size 512 --interp linear --angle $ang --iters 20 2>&1 | grep -v amdgpu.ids | sed "s/^/lin cfg=$tile /"
+done
+VT_TILE=$tile python3 tools/prof_case.py --size 1024 --interp linear --angle 45 --iters 10 2>&1 | grep -v amdgpu.ids | sed "s/^/lin cfg=$tile /"
+done
+for tile in 0 1 3; do
+for ang in 0 45 90; do
+  VT_TILE=$tile python3 tools/prof_case.py --size 512 --interp filt_bspline --angle $ang --iters 20 2>&1 | grep -v amdgpu.ids | sed "s/^/cub cfg=$tile /"
+done
+VT_TILE=$tile python3 tools/prof_case.py --size 1024 --interp filt_bspline --angle 45 --iters 10 2>&1 | grep -v amdgpu.ids | sed "s/^/cub cfg=$tile /"
+done

@@ -214,8 +214,9 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
             const double fl = std::floor(m[3]);
             for (int c = 0; c < zpair_config_count() && plan->kind != 5; ++c) {
                 if (v->force_cfg >= 0 && c != v->force_cfg) continue;
-                int th, tw, la;
-                zpair_config(c, &th, &tw, &la);
+                int th, tw, la, nt;
+                zpair_config(c, &th, &tw, &la, &nt);
+                const int vec_max = nt * march_max_it();
                 const int T[3] = {1, th, tw};
                 int L[3] = {0, 0, 0};
                 bool ok = true;
@@ -227,6 +228,9 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
                 }
                 if (!ok) continue;
                 L[2] = (L[2] + 1 + 1) & ~1;                      // origin aligned down by up to 1 position, even width
+                // box vs packed spans: on par at 512^3, packed 7 % faster at 1024^3 (fabric-bound) [measured]
+                bool zp_box = (int64_t)v->H * v->W <= 512 * 512;
+                if (const char* e = std::getenv("VT_MARCH_BOX")) zp_box = std::atoi(e) != 0;
                 int best_lx = L[2];
                 double best_f = 1e300;
                 for (int pad = 0; pad <= 30; pad += 2) {         // bank-pair index = (y*Lx + x) mod 32 for ds_read_b64
@@ -237,14 +241,22 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
                 }
                 if (const char* e = std::getenv("VT_LXPAD")) best_lx = L[2] + std::atoi(e);
                 L[2] = best_lx;
-                const int slot_floats = L[1] * L[2] * 2;
-                if (L[1] * (L[2] / 2) > march_vectors_max()) continue;
+                int slot_floats = L[1] * L[2] * 2;
+                if (!zp_box) {
+                    int rows = 0;
+                    // packed spans: vectors of 2 positions; the estimate counts 4-position vectors, so double it (loose)
+                    const int vecs = 2 * estimate_packed_vectors(m, th, tw, 1, &rows);
+                    if (rows > march_rows_max() || L[1] > march_rows_max()) continue;
+                    slot_floats = vecs * 4;
+                    if (vecs > vec_max) continue;
+                } else if (L[1] * (L[2] / 2) > vec_max) continue;
                 const int64_t bytes = (int64_t)(la + 1) * slot_floats * 4;
                 if (bytes > v->lds_limit) continue;
                 plan->kind = 5; plan->cfg = c; plan->td = 2; plan->th = th; plan->tw = tw;
                 plan->lds_bytes = (int)bytes;
                 p->Lz = la + 1; p->Ly = L[1]; p->Lx = L[2];
                 p->slot_floats = slot_floats;
+                p->flags = (flags & VT_KEEP_OUTSIDE) | (zp_box ? (1 << 20) : 0);
             }
             if (plan->kind == 5) {
                 const int T[3] = {1, plan->th, plan->tw};
@@ -286,8 +298,9 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
         if (const char* e = std::getenv("VT_MARCH_BOX")) march_box = std::atoi(e) != 0;
         for (int c = 0; c < march_config_count(); ++c) {
             if (v->force_cfg >= 0 && c != v->force_cfg) continue;
-            int th, tw, g, la;
-            march_config(c, &th, &tw, &g, &la);
+            int th, tw, g, la, nt;
+            march_config(c, &th, &tw, &g, &la, &nt);
+            const int vec_max = nt * march_max_it();
             const int T[3] = {1, th, tw};
             int L[3] = {0, 0, 0};
             bool ok = true;
@@ -300,7 +313,7 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
             if (!ok || L[1] > march_rows_max()) continue;
             int rows = 0;
             const int vecs = estimate_packed_vectors(m, th, tw, cubic ? 1 : 0, &rows);
-            if (vecs > march_vectors_max() || rows > march_rows_max()) continue;
+            if (vecs > vec_max || rows > march_rows_max()) continue;
             int slot_floats = vecs * 4;
             if (march_box) {
                 // full bounding box with the row stride (in 16-byte steps) that predicts the fewest bank conflicts for
@@ -314,7 +327,7 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
                 }
                 L[2] = best_lx;
                 slot_floats = L[1] * L[2];
-                if (L[1] * L[2] / 4 > march_vectors_max()) continue;
+                if (L[1] * L[2] / 4 > vec_max) continue;
             }
             const int ring = (la + 1) * g + halo2 + 1;
             const int64_t bytes = std::max<int64_t>((int64_t)ring * slot_floats * 4, 1024);

@@ -104,14 +104,14 @@ void tile_config(int idx, int* td, int* th, int* tw);
 hipError_t launch_affine_tiled(int cfg, int interp, bool zsep, const float* src, float* out, const float* zeros16,
                                const AffineParams& p, int grid, int lds_bytes, hipStream_t stream);
 int march_config_count();
-void march_config(int idx, int* th, int* tw, int* g, int* la);
+void march_config(int idx, int* th, int* tw, int* g, int* la, int* nt);
 int zpair_config_count();
-void zpair_config(int idx, int* th, int* tw, int* la);
+void zpair_config(int idx, int* th, int* tw, int* la, int* nt);
 hipError_t launch_affine_zpair(int cfg, int interp, const float* src2, float* out, const AffineParams& p,
                                int grid, int lds_bytes, hipStream_t stream);
 hipError_t launch_relayout_zpair(const float* src, float* dst, int D, int H, int W, int P, int P2, hipStream_t stream);
 int march_rows_max();
-int march_vectors_max();
+int march_max_it();
 int interp_kind(int interp);
 hipError_t init_march_kernels();
 hipError_t launch_affine_march(int cfg, int interp, const float* src, float* out, const AffineParams& p,

@@ -77,17 +77,17 @@ __device__ __forceinline__ float plane_partial_rows(const float* __restrict__ pl
 constexpr int kRowsMax = 64;      // source rows a tile's footprint may span (host-checked)
 constexpr int kMaxIt = 4;         // packed footprint <= 1024 vectors (16 KiB) per plane (host-checked via slot size)
 
-template <int KIND, int TH, int TW, int G, int LA>
-__global__ __launch_bounds__(256) void affine_march_zsep(const float* __restrict__ src, float* __restrict__ out,
+template <int KIND, int TH, int TW, int G, int LA, int NT>
+__global__ __launch_bounds__(NT) void affine_march_zsep(const float* __restrict__ src, float* __restrict__ out,
                                                           const AffineParams p)
 {
-    static_assert(256 % TW == 0 && TH % (256 / TW) == 0, "tile/thread mapping");
+    static_assert(NT % TW == 0 && TH % (NT / TW) == 0 && NT % 64 == 0, "tile/thread mapping");
     constexpr bool CUBIC = KIND != 0;
     constexpr int HALO = CUBIC ? 1 : 0;
     constexpr int NR = 2 + 2 * HALO;              // tap rows (and columns) per pixel
     constexpr int NC = 2 * HALO + 1;              // carried partials per pixel
     constexpr int R = (LA + 1) * G + 2 * HALO + 1;   // ring slots: live group + LA groups in flight
-    constexpr int RP = 256 / TW;
+    constexpr int RP = NT / TW;
     constexpr int NPIX = TH / RP;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void affine_march_zsep(const float* __restrict
         nvec = Ly * nvx;
 #pragma unroll
         for (int it = 0; it < kMaxIt; ++it) {
-            const int v = tid + 256 * it;
+            const int v = tid + NT * it;
             const int y = v / nvx;
             const int cx = v - y * nvx;
             const int gy = o1 + y, gx = o2 + 4 * cx;
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void affine_march_zsep(const float* __restrict
         nvec = tab[2 * kRowsMax];
 #pragma unroll
         for (int it = 0; it < kMaxIt; ++it) {
-            const int v = tid + 256 * it;
+            const int v = tid + NT * it;
             int y = 0;
             if (v < nvec) {
                 int a = 0, b = Ly - 1;                // largest row whose first vector is <= v
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void affine_march_zsep(const float* __restrict
         __syncthreads();                          // the table is dead from here on; the ring may be written
     }
 
-    if (nvec * 4 > slot_floats || nvec > 256 * kMaxIt) {
+    if (nvec * 4 > slot_floats || nvec > NT * kMaxIt) {
         // The footprint does not fit the slot planned on the host: gather this workgroup's voxels from global memory
         // (same arithmetic as affine_direct).
 #pragma unroll
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void affine_march_zsep(const float* __restrict
     const int wave_first = __builtin_amdgcn_readfirstlane(tid & ~63);
     int nit_w = 0;                                // direct-to-LDS loads this wave issues per plane
 #pragma unroll
-    for (int it = 0; it < kMaxIt; ++it) nit_w += (wave_first + 256 * it < nvec) ? 1 : 0;
+    for (int it = 0; it < kMaxIt; ++it) nit_w += (wave_first + NT * it < nvec) ? 1 : 0;
     const int plane_bytes = p.sH * p.sP * 4;      // < 2^31 (host-checked)
     // one buffer descriptor for the whole chunk, based at the first resident plane it touches; the plane is selected with
     // the scalar offset operand
@@ -281,10 +281,10 @@ __global__ __launch_bounds__(256) void affine_march_zsep(const float* __restrict
         float* dst = lds + slot * slot_floats + 4 * wave_first;
 #pragma unroll
         for (int it = 0; it < kMaxIt; ++it) {
-            if (wave_first + 256 * it < nvec) {               // wave-uniform
+            if (wave_first + NT * it < nvec) {               // wave-uniform
                 const int off = plane_ok ? voff[it] : p.zero_off;
-                if (tid + 256 * it < nvec)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + 1024 * it),
+                if (tid + NT * it < nvec)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + (4 * NT) * it),
                                                              16, off, soff, 0, 0);
             }
         }
@@ -391,15 +391,15 @@ __global__ __launch_bounds__(256) void affine_march_zsep(const float* __restrict
 // every plane's partial is consumed exactly once (the z history lives in registers).
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-template <int KIND, int TH, int TW, int LA>
-__global__ __launch_bounds__(256) void affine_march_zpair(const float* __restrict__ src2, float* __restrict__ out,
+template <int KIND, int TH, int TW, int LA, int NT>
+__global__ __launch_bounds__(NT) void affine_march_zpair(const float* __restrict__ src2, float* __restrict__ out,
                                                            const AffineParams p)
 {
     static_assert(KIND != 0, "cubic only");
-    static_assert(256 % TW == 0 && TH % (256 / TW) == 0, "tile/thread mapping");
+    static_assert(NT % TW == 0 && TH % (NT / TW) == 0 && NT % 64 == 0, "tile/thread mapping");
     constexpr int HALO = 1;
     constexpr int R = LA + 1;                     // ring slots (plane pairs)
-    constexpr int RP = 256 / TW;
+    constexpr int RP = NT / TW;
     constexpr int NPIX = TH / RP;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -449,26 +449,14 @@ __global__ __launch_bounds__(256) void affine_march_zpair(const float* __restric
     const int o1 = (int)floor(lo[1]) - HALO;
     const int o2 = ((int)floor(lo[2]) - HALO) & ~1;            // 16-byte vectors hold 2 positions x 2 planes
     const int Ly = p.Ly, Lx = p.Lx;                              // Lx in positions, even
-    const int nvx = Lx >> 1;
-    const int nvec = Ly * nvx;
-    const int slot_floats = p.slot_floats;                       // = Ly * Lx * 2
+    const int slot_floats = p.slot_floats;
+    const bool box_mode = (p.flags & (1 << 20)) != 0;
+    const double by = base[1] - (double)o1, bx = base[2] - (double)o2;
 
-    int voff[kMaxIt];
-#pragma unroll
-    for (int it = 0; it < kMaxIt; ++it) {
-        const int v = tid + 256 * it;
-        const int y = v / nvx;
-        const int cx = v - y * nvx;
-        const int gy = o1 + y, gx = o2 + 2 * cx;
-        const bool ok = (v < nvec) && (unsigned)gy < (unsigned)p.sH && (unsigned)gx < (unsigned)(p.sP2 >> 1);
-        voff[it] = ok ? (gy * p.sP2 + 2 * gx) * 4 : p.zero_off2;
-    }
-
-    int q[NPIX];                                  // float offset of tap (iy-1, ix-1) inside a pair slot
+    int iy[NPIX], ix[NPIX];
     float wy[NPIX][4], wx[NPIX][4];
     bool in_yx[NPIX];
     int64_t ooff[NPIX];
-    const double by = base[1] - (double)o1, bx = base[2] - (double)o2;
 #pragma unroll
     for (int px = 0; px < NPIX; ++px) {
         const int j = jh0 + px * RP;
@@ -477,11 +465,118 @@ __global__ __launch_bounds__(256) void affine_march_zpair(const float* __restric
         const double fyd = floor(sy), fxd = floor(sx);
         cubic_weights<KIND == 2>((float)(sy - fyd), wy[px]);
         cubic_weights<KIND == 2>((float)(sx - fxd), wx[px]);
-        q[px] = 2 * (__mul24((int)fyd - HALO, Lx) + ((int)fxd - HALO));
+        iy[px] = (int)fyd;
+        ix[px] = (int)fxd;
         const double ey = sy + (double)o1, ex = sx + (double)o2;
         in_yx[px] = all_valid || ((ey >= p.vlo[1]) && (ey < p.vhi[1]) && (ex >= p.vlo[2]) && (ex < p.vhi[2]));
         ooff[px] = ((int64_t)(h0 + j)) * p.oW + (w0 + kw);
     }
+
+    int voff[kMaxIt];
+    int q[NPIX][4];                               // float offset of tap (iy-1+bb, ix-1) inside a pair slot
+    int nvec;
+    if (box_mode) {
+        const int nvx = Lx >> 1;
+        nvec = Ly * nvx;
+#pragma unroll
+        for (int it = 0; it < kMaxIt; ++it) {
+            const int v = tid + NT * it;
+            const int y = v / nvx;
+            const int cx = v - y * nvx;
+            const int gy = o1 + y, gx = o2 + 2 * cx;
+            const bool ok = (v < nvec) && (unsigned)gy < (unsigned)p.sH && (unsigned)gx < (unsigned)(p.sP2 >> 1);
+            voff[it] = ok ? (gy * p.sP2 + 2 * gx) * 4 : p.zero_off2;
+        }
+#pragma unroll
+        for (int px = 0; px < NPIX; ++px)
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) q[px][bb] = 2 * (__mul24(iy[px] - HALO + bb, Lx) + (ix[px] - HALO));
+    } else {
+        // packed row spans (see affine_march_zsep); spans are aligned to 2 positions = one 16-byte vector
+        int* tab = reinterpret_cast<int*>(lds);
+        const int lane = tid & 63;
+        if (tid < kRowsMax) {
+            int mn, mx;
+            const bool used = (tid < Ly) && march_row_span(p.m[5], p.m[6], p.m[9], p.m[10], by, bx, tid, TH, TW, HALO, &mn, &mx);
+            const int x0 = used ? (mn & ~1) : 0;
+            const int nv = used ? (((mx - x0) >> 1) + 1) : 0;
+            int incl = nv;
+#pragma unroll
+            for (int s2 = 1; s2 < 64; s2 <<= 1) {
+                const int up = __shfl_up(incl, s2);
+                if (lane >= s2) incl += up;
+            }
+            tab[tid] = x0;
+            tab[kRowsMax + tid] = incl - nv;
+            if (tid == kRowsMax - 1) tab[2 * kRowsMax] = incl;
+        }
+        __syncthreads();
+        nvec = tab[2 * kRowsMax];
+#pragma unroll
+        for (int it = 0; it < kMaxIt; ++it) {
+            const int v = tid + NT * it;
+            int y = 0;
+            if (v < nvec) {
+                int a = 0, b = Ly - 1;
+                while (a < b) {
+                    const int mid = (a + b + 1) >> 1;
+                    if (tab[kRowsMax + mid] <= v) a = mid; else b = mid - 1;
+                }
+                y = a;
+            }
+            const int cx = v - tab[kRowsMax + y];
+            const int gy = o1 + y, gx = o2 + tab[y] + 2 * cx;
+            const bool ok = (v < nvec) && (unsigned)gy < (unsigned)p.sH && (unsigned)gx < (unsigned)(p.sP2 >> 1);
+            voff[it] = ok ? (gy * p.sP2 + 2 * gx) * 4 : p.zero_off2;
+        }
+#pragma unroll
+        for (int px = 0; px < NPIX; ++px)
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                const int row = min(max(iy[px] - HALO + bb, 0), kRowsMax - 1);
+                q[px][bb] = 4 * tab[kRowsMax + row] + 2 * (ix[px] - HALO - tab[row]);
+            }
+        __syncthreads();
+    }
+    if (nvec * 4 > slot_floats || nvec > NT * kMaxIt) {
+        // footprint larger than planned: gather from the plain layout is not available here (src2 is the pair copy), so
+        // read the pair copy directly -- element (z, y, x) sits at ((z>>1)*H + y)*P2 + 2x + (z&1)
+#pragma unroll
+        for (int px = 0; px < NPIX; ++px) {
+            const int h = h0 + jh0 + px * RP, w = w0 + kw;
+            if (h >= p.oH || w >= p.oW) continue;
+            float wzl[4];
+            cubic_weights<KIND == 2>(p.fz, wzl);
+            for (int d = d_begin; d < d_end; ++d) {
+                const double ez = (double)d + p.m[3];
+                const bool inside = in_yx[px] && (ez >= p.vlo[0]) && (ez < p.vhi[0]);
+                float val = 0.f;
+                if (inside) {
+                    for (int c = 0; c < 4; ++c) {
+                        const int z = d + p.zoff - 1 + c;
+                        float accy = 0.f;
+                        for (int bb = 0; bb < 4; ++bb) {
+                            const int y = o1 + iy[px] - 1 + bb;
+                            float accx = 0.f;
+                            for (int a2 = 0; a2 < 4; ++a2) {
+                                const int x = o2 + ix[px] - 1 + a2;
+                                float tv = 0.f;
+                                if ((unsigned)z < (unsigned)p.sD && (unsigned)y < (unsigned)p.sH && (unsigned)x < (unsigned)p.sW)
+                                    tv = src2[((int64_t)(z >> 1) * p.sH + y) * p.sP2 + 2 * x + (z & 1)];
+                                accx = (a2 == 0) ? wx[px][0] * tv : fmaf(wx[px][a2], tv, accx);
+                            }
+                            accy = fmaf(wy[px][bb], accx, accy);
+                        }
+                        val = fmaf(wzl[c], accy, val);
+                    }
+                }
+                if (inside) out[ooff[px] + (int64_t)d * ostride] = val;
+                else if (!keep) out[ooff[px] + (int64_t)d * ostride] = 0.0f;
+            }
+        }
+        return;
+    }
+
     float wz[4];
     cubic_weights<KIND == 2>(p.fz, wz);
 
@@ -501,10 +596,10 @@ __global__ __launch_bounds__(256) void affine_march_zpair(const float* __restric
         float* dst = lds + slot * slot_floats + 4 * wave_first;
 #pragma unroll
         for (int it = 0; it < kMaxIt; ++it) {
-            if (wave_first + 256 * it < nvec) {               // wave-uniform
+            if (wave_first + NT * it < nvec) {               // wave-uniform
                 const int off = pair_ok ? voff[it] : p.zero_off2;
-                if (tid + 256 * it < nvec)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + 1024 * it),
+                if (tid + NT * it < nvec)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + (4 * NT) * it),
                                                              16, off, soff, 0, 0);
             }
         }
@@ -546,7 +641,7 @@ __global__ __launch_bounds__(256) void affine_march_zpair(const float* __restric
         for (int px = 0; px < NPIX; ++px) {
 #pragma unroll
             for (int bb = 0; bb < 4; ++bb) {
-                const unsigned addr = pl_addr + 4u * (unsigned)(q[px] + 2 * bb * Lx);
+                const unsigned addr = pl_addr + 4u * (unsigned)q[px][bb];
                 asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %4 offset:16\n\tds_read_b64 %3, %4 offset:24"
                              : "=&v"(tap[px][4 * bb]), "=&v"(tap[px][4 * bb + 1]), "=&v"(tap[px][4 * bb + 2]), "=&v"(tap[px][4 * bb + 3])
                              : "v"(addr));
@@ -646,63 +741,75 @@ hipError_t launch_relayout_zpair(const float* src, float* dst, int D, int H, int
 // host side
 // ---------------------------------------------------------------------------------------------------
 typedef void (*march_fn)(const float*, float*, const AffineParams);
-struct MarchCfg { int th, tw, g, la; };
+struct MarchCfg { int th, tw, g, la, nt; };
 static const MarchCfg kMarch[] = {
     // in order of preference (the planner takes the first that fits LDS)
-    {16, 32, 2, 1},   // 0: two pixels per thread, 128-byte store segments, shallow ring (most workgroups per CU)
-    {8, 32, 2, 1},    // 1: one pixel per thread, half the footprint
-    {16, 32, 2, 2},   // 2: deeper ring (experiments: never faster on MI355X)
-    {16, 32, 2, 3},   // 3
-    {16, 32, 4, 1},   // 4: fewer barriers
-    {32, 32, 2, 1},   // 5: four pixels per thread, longer row spans
+    {16, 32, 2, 1, 256},   // 0: two pixels per thread, 128-byte store rows, shallow ring (most workgroups per CU)
+    {8, 32, 2, 1, 256},    // 1: one pixel per thread, half the footprint
+    {16, 64, 2, 1, 512},   // 2: 512 threads, 256-byte store rows (measured: no faster than 0)
+    {16, 32, 2, 2, 256},   // 3: deeper ring (experiments: never faster on MI355X)
+    {16, 32, 4, 1, 256},   // 4: fewer barriers
+    {32, 64, 2, 1, 1024},  // 5: 1024 threads
 };
 int march_config_count() { return (int)(sizeof(kMarch) / sizeof(kMarch[0])); }
-void march_config(int idx, int* th, int* tw, int* g, int* la) { *th = kMarch[idx].th; *tw = kMarch[idx].tw; *g = kMarch[idx].g; *la = kMarch[idx].la; }
+void march_config(int idx, int* th, int* tw, int* g, int* la, int* nt)
+{
+    *th = kMarch[idx].th; *tw = kMarch[idx].tw; *g = kMarch[idx].g; *la = kMarch[idx].la; *nt = kMarch[idx].nt;
+}
 int march_rows_max() { return kRowsMax; }
-int march_vectors_max() { return 256 * kMaxIt; }
+int march_max_it() { return kMaxIt; }
 
-template <int TH, int TW, int G, int LA>
+template <int TH, int TW, int G, int LA, int NT>
 static march_fn pick_march(int kind)
 {
     switch (kind) {
-        case 0: return affine_march_zsep<0, TH, TW, G, LA>;
-        case 1: return affine_march_zsep<1, TH, TW, G, LA>;
-        default: return affine_march_zsep<2, TH, TW, G, LA>;
+        case 0: return affine_march_zsep<0, TH, TW, G, LA, NT>;
+        case 1: return affine_march_zsep<1, TH, TW, G, LA, NT>;
+        default: return affine_march_zsep<2, TH, TW, G, LA, NT>;
     }
 }
 static march_fn march_entry(int cfg, int kind)
 {
     switch (cfg) {
-        case 0: return pick_march<16, 32, 2, 1>(kind);
-        case 1: return pick_march<8, 32, 2, 1>(kind);
-        case 2: return pick_march<16, 32, 2, 2>(kind);
-        case 3: return pick_march<16, 32, 2, 3>(kind);
-        case 4: return pick_march<16, 32, 4, 1>(kind);
-        default: return pick_march<32, 32, 2, 1>(kind);
+        case 0: return pick_march<16, 32, 2, 1, 256>(kind);
+        case 1: return pick_march<8, 32, 2, 1, 256>(kind);
+        case 2: return pick_march<16, 64, 2, 1, 512>(kind);
+        case 3: return pick_march<16, 32, 2, 2, 256>(kind);
+        case 4: return pick_march<16, 32, 4, 1, 256>(kind);
+        default: return pick_march<32, 64, 2, 1, 1024>(kind);
     }
 }
 
 typedef void (*zpair_fn)(const float*, float*, const AffineParams);
+struct ZpairCfg { int th, tw, la, nt; };
+static const ZpairCfg kZpair[] = {
+    {16, 32, 1, 256},    // 0
+    {8, 32, 1, 256},     // 1
+    {16, 64, 1, 512},    // 2 (measured: slower than 0)
+    {32, 64, 1, 1024},   // 3 (measured: on par with 0 at 0/90 degrees, slower at 45)
+};
+template <int TH, int TW, int LA, int NT>
+static zpair_fn pick_zpair(int kind) { return kind == 1 ? affine_march_zpair<1, TH, TW, LA, NT> : affine_march_zpair<2, TH, TW, LA, NT>; }
 static zpair_fn zpair_entry(int cfg, int kind)
 {
-    // cfg 0: 16x32 tile, one pair in flight; cfg 1: 8x32; cfg 2: 16x32, two pairs in flight
     switch (cfg) {
-        case 0: return kind == 1 ? affine_march_zpair<1, 16, 32, 1> : affine_march_zpair<2, 16, 32, 1>;
-        case 1: return kind == 1 ? affine_march_zpair<1, 8, 32, 1> : affine_march_zpair<2, 8, 32, 1>;
-        default: return kind == 1 ? affine_march_zpair<1, 16, 32, 2> : affine_march_zpair<2, 16, 32, 2>;
+        case 0: return pick_zpair<16, 32, 1, 256>(kind);
+        case 1: return pick_zpair<8, 32, 1, 256>(kind);
+        case 2: return pick_zpair<16, 64, 1, 512>(kind);
+        default: return pick_zpair<32, 64, 1, 1024>(kind);
     }
 }
-int zpair_config_count() { return 3; }
-void zpair_config(int idx, int* th, int* tw, int* la)
+int zpair_config_count() { return (int)(sizeof(kZpair) / sizeof(kZpair[0])); }
+void zpair_config(int idx, int* th, int* tw, int* la, int* nt)
 {
-    *th = (idx == 1) ? 8 : 16; *tw = 32; *la = (idx == 2) ? 2 : 1;
+    *th = kZpair[idx].th; *tw = kZpair[idx].tw; *la = kZpair[idx].la; *nt = kZpair[idx].nt;
 }
 
 hipError_t launch_affine_zpair(int cfg, int interp, const float* src2, float* out, const AffineParams& p,
                                int grid, int lds_bytes, hipStream_t stream)
 {
     zpair_fn fn = zpair_entry(cfg, interp_kind(interp));
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds_bytes, stream, src2, out, p);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kZpair[cfg].nt), lds_bytes, stream, src2, out, p);
     return hipGetLastError();
 }
 
@@ -727,7 +834,7 @@ hipError_t launch_affine_march(int cfg, int interp, const float* src, float* out
                                int grid, int lds_bytes, hipStream_t stream)
 {
     march_fn fn = march_entry(cfg, interp_kind(interp));
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds_bytes, stream, src, out, p);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kMarch[cfg].nt), lds_bytes, stream, src, out, p);
     return hipGetLastError();
 }
 
