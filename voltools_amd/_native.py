@@ -145,6 +145,7 @@ class DeviceArray:
 
     def __init__(self, shape, device: int = 0, zero: bool = False):
         self.shape = tuple(int(s) for s in shape)
+        self.ndim = len(self.shape)
         self.dtype = np.dtype(np.float32)
         self.device = int(device)
         self.size = int(np.prod(self.shape))

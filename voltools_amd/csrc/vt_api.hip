@@ -567,7 +567,8 @@ int create_common(int dev, int D, int H, int W, int interp, const float* data, i
     VT_HIPC(hipMalloc(reinterpret_cast<void**>(&v->d_zeros), 256));
     VT_HIPC(hipMemsetAsync(v->d_zeros, 0, 256, v->stream));
     const hipMemcpyKind kind = (cflags & VT_SRC_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    VT_HIPC(hipMemsetAsync(v->d_src, 0, bytes, v->stream));
+    // only the pad columns need zeroing (a full memset would cost another 4 B/voxel of HBM writes)
+    VT_HIPC(hipMemset2DAsync(v->d_src + W, (size_t)v->P * sizeof(float), 0, (size_t)(v->P - W) * sizeof(float), (size_t)D * H, v->stream));
     VT_HIPC(hipMemcpy2DAsync(v->d_src, (size_t)v->P * sizeof(float), data, (size_t)W * sizeof(float),
                              (size_t)W * sizeof(float), (size_t)D * H, kind, v->stream));
 
@@ -575,7 +576,7 @@ int create_common(int dev, int D, int H, int W, int interp, const float* data, i
         float* d_tmp = nullptr;
         VT_HIPC(hipMalloc(reinterpret_cast<void**>(&d_tmp), bytes));
         {
-            hipError_t em = hipMemsetAsync(d_tmp, 0, bytes, v->stream);
+            hipError_t em = hipMemset2DAsync(d_tmp + W, (size_t)v->P * sizeof(float), 0, (size_t)(v->P - W) * sizeof(float), (size_t)D * H, v->stream);
             if (em != hipSuccess) { hipFree(d_tmp); return cleanup(fail((int)em, "memset: %s", hipGetErrorString(em))); }
         }
         float* res = nullptr;
