@@ -115,7 +115,13 @@ def main():
 
     # synthetic data: uniform [0,1) float32, seeded per rank
     vol = np.random.RandomState(rank).random_sample((n, n, n)).astype(np.float32)
-    if world > 1:
+    use_slab = world > 1 or os.environ.get('BENCH_FORCE_SLAB') == '1'
+    if use_slab and dist is None:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', local_rank))
+    if use_slab:
         from voltools_amd.distributed import SlabVolume
         sv = SlabVolume(vol, interpolation=interp, device=dev, group=dist.group.WORLD)
     else:

@@ -26,6 +26,7 @@
 #include "vt_device.h"
 
 #include <climits>
+#include <type_traits>
 
 namespace vt {
 
@@ -86,7 +87,8 @@ __global__ __launch_bounds__(NT) void affine_march_zsep(const float* __restrict_
     constexpr int HALO = CUBIC ? 1 : 0;
     constexpr int NR = 2 + 2 * HALO;              // tap rows (and columns) per pixel
     constexpr int NC = 2 * HALO + 1;              // carried partials per pixel
-    constexpr int R = (LA + 1) * G + 2 * HALO + 1;   // ring slots: live group + LA groups in flight
+    static_assert(LA == 1 || LA == 2, "ring depth");
+    constexpr int R = (LA + 1) * G + 2 * HALO + 1;   // ring slots: live group + one group in flight (+ halo planes)
     constexpr int RP = NT / TW;
     constexpr int NPIX = TH / RP;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -119,7 +121,6 @@ __global__ __launch_bounds__(NT) void affine_march_zsep(const float* __restrict_
     const bool keep = (p.flags & VT_KEEP_OUTSIDE) != 0;
     // every lane of the workgroup stores exactly one value per pixel and plane -> the number of stores a wave has in
     // flight is known, and the wait before the barrier can leave them (and later loads) outstanding
-    const bool exact_stores = (h0 + TH <= p.oH) && (w0 + TW <= p.oW) && ((d_end - d_begin) % G == 0) && (all_valid || !keep);
     const int64_t ostride = (int64_t)p.oH * p.oW;
     const int kw = tid % TW;
     const int jh0 = tid / TW;
@@ -264,9 +265,6 @@ __global__ __launch_bounds__(NT) void affine_march_zsep(const float* __restrict_
     }
 
     const int wave_first = __builtin_amdgcn_readfirstlane(tid & ~63);
-    int nit_w = 0;                                // direct-to-LDS loads this wave issues per plane
-#pragma unroll
-    for (int it = 0; it < kMaxIt; ++it) nit_w += (wave_first + NT * it < nvec) ? 1 : 0;
     const int plane_bytes = p.sH * p.sP * 4;      // < 2^31 (host-checked)
     // one buffer descriptor for the whole chunk, based at the first resident plane it touches; the plane is selected with
     // the scalar offset operand
@@ -274,110 +272,159 @@ __global__ __launch_bounds__(NT) void affine_march_zsep(const float* __restrict_
     const int P_base = max(0, min(P_first, p.sD - 1));
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(src) + (int64_t)P_base * plane_bytes), 0, 0x7fffffff, 0x00020000);
-
-    auto issue_plane = [&](int P, int slot) {
-        const bool plane_ok = (unsigned)P < (unsigned)p.sD;
-        const int soff = plane_ok ? (P - P_base) * plane_bytes : 0;
-        float* dst = lds + slot * slot_floats + 4 * wave_first;
-#pragma unroll
-        for (int it = 0; it < kMaxIt; ++it) {
-            if (wave_first + NT * it < nvec) {               // wave-uniform
-                const int off = plane_ok ? voff[it] : p.zero_off;
-                if (tid + NT * it < nvec)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + (4 * NT) * it),
-                                                             16, off, soff, 0, 0);
-            }
-        }
-    };
-
     const float fz = p.fz;
     float wz[4] = {0.f, 0.f, 0.f, 0.f};
     if constexpr (CUBIC) cubic_weights<KIND == 2>(fz, wz);
+    const int ngroups = (d_end - d_begin + G - 1) / G;
+#ifdef VT_EXPERIMENTS      // make EXTRA=-DVT_EXPERIMENTS: VT_EXP_NOSTORE / VT_EXP_NOLOAD ablations
+    const bool no_stores = (p.flags & (1 << 21)) != 0, no_loads = (p.flags & (1 << 22)) != 0;
+#else
+    constexpr bool no_stores = false, no_loads = false;
+#endif
 
     // ---- pipeline ----
-    // order of a wave's vector-memory operations:  loads(g0 .. g0+LA-1) | [loads(g+LA) stores(g)] for g = g0, g0+1, ...
-    // => when group g is about to be computed, everything issued after loads(g) may stay outstanding.
-    int P_next = P_first;                         // next source plane to stage
-    int slot_next = 0;
-    auto issue_planes = [&](int count) {
-        for (int c = 0; c < count; ++c) {
+    // The CU has ONE scalar unit: the steady-state loop is written so that it needs a few dozen scalar instructions per
+    // group instead of a few hundred (measured: with neither loads nor stores the first version still took 62 % of its
+    // run time, 70 % of that on the scalar unit).  Hence: the number of staging instructions per plane (NIT) is a
+    // compile-time constant selected by one switch, only the last of them is lane-masked, and the common case -- tile
+    // fully inside the valid region and the output -- has no per-voxel predicates at all.
+    // Order of a wave's vector-memory operations: loads(0) | [loads(g+1) stores(g)] for g = 0, 1, ...  => when group g is
+    // about to be computed only the stores of group g-1 were issued after its loads.
+    auto run = [&](auto nit_c, auto fast_c) {
+        constexpr int NIT = decltype(nit_c)::value;
+        constexpr bool FAST = decltype(fast_c)::value;
+        const bool last_ok = tid + NT * (NIT - 1) < nvec;
+        auto issue_plane = [&](int P, int slot) {
+            if (no_loads) return;
+            const bool plane_ok = (unsigned)P < (unsigned)p.sD;                  // wave-uniform
+            float* dst = lds + slot * slot_floats + 4 * wave_first;
+            if (plane_ok) {
+                const int soff = (P - P_base) * plane_bytes;
+#pragma unroll
+                for (int it = 0; it < NIT - 1; ++it)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + (4 * NT) * it), 16, voff[it], soff, 0, 0);
+                if (last_ok)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + (4 * NT) * (NIT - 1)), 16, voff[NIT - 1], soff, 0, 0);
+            } else {                                                             // plane outside the volume: border zeros
+#pragma unroll
+                for (int it = 0; it < NIT - 1; ++it)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + (4 * NT) * it), 16, p.zero_off, 0, 0, 0);
+                if (last_ok)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + (4 * NT) * (NIT - 1)), 16, p.zero_off, 0, 0, 0);
+            }
+        };
+        int P_next = P_first;                     // next source plane to stage
+        int slot_next = 0;
+        for (int c = 0; c < G + 2 * HALO + 1; ++c) {          // group 0 with its halo planes
             issue_plane(P_next, slot_next);
             ++P_next;
             slot_next = (slot_next + 1 == R) ? 0 : slot_next + 1;
         }
-    };
-    const int ngroups = (d_end - d_begin + G - 1) / G;
-    issue_planes(G + 2 * HALO + 1);               // group 0 (with its halo planes)
-    for (int a = 1; a < LA; ++a) issue_planes(G); // groups 1 .. LA-1
-    const int loads_per_group = G * nit_w;
-    float carry[NPIX][NC];
-    int slot_cur = 0;                             // slot of source plane zs(d) - HALO
-    int g = 0;
-    for (int d = d_begin; d < d_end; d += G, ++g) {
-        if constexpr (LA == 1) {
-            // nothing but the previous group's stores was issued after this group's loads
-            if (exact_stores && g > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * NPIX) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            int allow = 0;
-            if (exact_stores) allow = min(LA - 1, ngroups - 1 - g) * loads_per_group + min(g, LA) * (G * NPIX);
-            else if (g == 0) allow = min(LA - 1, ngroups - 1) * loads_per_group;
-            wait_vmcnt_le(allow);
-        }
-        __builtin_amdgcn_s_barrier();             // everyone's loads landed; everyone is done with the slots reused next
-        if (g + LA < ngroups) issue_planes(G);
-        if (g == 0) {
+        if constexpr (LA == 2) {
+            if (ngroups > 1) {
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const int sl = (slot_cur + c >= R) ? slot_cur + c - R : slot_cur + c;
-                const float* pl = lds + sl * slot_floats;
-#pragma unroll
-                for (int px = 0; px < NPIX; ++px)
-                    carry[px][c] = plane_partial_rows<KIND, NR>(pl, q[px], fy[px], fx[px], wy[px], wx[px]);
-            }
-        }
-        const int64_t dofs = (int64_t)(d - d_begin) * ostride;      // wave-uniform
-#pragma unroll
-        for (int i = 0; i < G; ++i) {
-            int sl = slot_cur + NC + i;
-            sl = (sl >= R) ? sl - R : sl;
-            const float* pl = lds + sl * slot_floats;
-            bool z_ok = true;
-            if (!all_valid) {
-                const double ez = (double)(d + i) + p.m[3];
-                z_ok = (ez >= p.vlo[0]) && (ez < p.vhi[0]);
-            }
-            float val[NPIX];
-#pragma unroll
-            for (int px = 0; px < NPIX; ++px) {
-                const float pn = plane_partial_rows<KIND, NR>(pl, q[px], fy[px], fx[px], wy[px], wx[px]);
-                if constexpr (!CUBIC) {
-                    val[px] = fmaf(fz, pn - carry[px][0], carry[px][0]);
-                    carry[px][0] = pn;
-                } else {
-                    float acc = wz[0] * carry[px][0];
-                    acc = fmaf(wz[1], carry[px][1], acc);
-                    acc = fmaf(wz[2], carry[px][2], acc);
-                    val[px] = fmaf(wz[3], pn, acc);
-                    carry[px][0] = carry[px][1]; carry[px][1] = carry[px][2]; carry[px][2] = pn;
+                for (int c = 0; c < G; ++c) {                 // group 1
+                    issue_plane(P_next, slot_next);
+                    ++P_next;
+                    slot_next = (slot_next + 1 == R) ? 0 : slot_next + 1;
                 }
             }
-            if (exact_stores) {
+        }
+        // staging instructions this wave issues per plane: NIT, or NIT-1 when none of its lanes is in the last one
+        const bool wave_has_last = __builtin_amdgcn_readfirstlane(tid & ~63) + NT * (NIT - 1) < nvec;
+        float carry[NPIX][NC];
+        int slot_cur = 0;                         // slot of source plane zs(d) - HALO
+        int64_t dofs = 0;                         // element offset of output plane d relative to d_begin (wave-uniform)
+        for (int g = 0; g < ngroups; ++g, dofs += (int64_t)G * ostride) {
+            if constexpr (LA == 1) {
+                if (FAST && g > 0 && !no_stores) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * NPIX) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                // issued after loads(g): stores(g-2), loads(g+1), stores(g-1)   (steady state, g >= 2 and g+1 < ngroups)
+                if (FAST && g >= 2 && g + 1 < ngroups && !no_stores) {
+                    if (wave_has_last) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G * NPIX + G * NIT) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G * NPIX + G * (NIT - 1)) : "memory");
+                } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();         // everyone's loads landed; everyone is done with the slots reused next
+            if (g + LA < ngroups) {
 #pragma unroll
-                for (int px = 0; px < NPIX; ++px)
-                    out[ooff[px] + dofs + i * ostride] = (in_yx[px] && z_ok) ? val[px] : 0.0f;
-            } else if (d + i < d_end) {
+                for (int c = 0; c < G; ++c) {
+                    issue_plane(P_next, slot_next);
+                    ++P_next;
+                    slot_next = (slot_next + 1 == R) ? 0 : slot_next + 1;
+                }
+            }
+            if (g == 0) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const float* pl = lds + c * slot_floats;
+#pragma unroll
+                    for (int px = 0; px < NPIX; ++px)
+                        carry[px][c] = plane_partial_rows<KIND, NR>(pl, q[px], fy[px], fx[px], wy[px], wx[px]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                int sl = slot_cur + NC + i;
+                sl = (sl >= R) ? sl - R : sl;
+                const float* pl = lds + sl * slot_floats;
+                float val[NPIX];
 #pragma unroll
                 for (int px = 0; px < NPIX; ++px) {
-                    if (h0 + jh0 + px * RP < p.oH && w0 + kw < p.oW) {
-                        if (in_yx[px] && z_ok) out[ooff[px] + dofs + i * ostride] = val[px];
-                        else if (!keep) out[ooff[px] + dofs + i * ostride] = 0.0f;
+                    const float pn = plane_partial_rows<KIND, NR>(pl, q[px], fy[px], fx[px], wy[px], wx[px]);
+                    if constexpr (!CUBIC) {
+                        val[px] = fmaf(fz, pn - carry[px][0], carry[px][0]);
+                        carry[px][0] = pn;
+                    } else {
+                        float acc = wz[0] * carry[px][0];
+                        acc = fmaf(wz[1], carry[px][1], acc);
+                        acc = fmaf(wz[2], carry[px][2], acc);
+                        val[px] = fmaf(wz[3], pn, acc);
+                        carry[px][0] = carry[px][1]; carry[px][1] = carry[px][2]; carry[px][2] = pn;
+                    }
+                }
+                if constexpr (FAST) {
+                    if (!no_stores) {
+#pragma unroll
+                        for (int px = 0; px < NPIX; ++px) out[ooff[px] + dofs + i * ostride] = val[px];
+                    } else if (val[0] == 12345.678f) out[0] = val[0];           // keep the values alive
+                } else {
+                    const int d = d_begin + g * G + i;
+                    const double ez = (double)d + p.m[3];
+                    const bool z_ok = (ez >= p.vlo[0]) && (ez < p.vhi[0]);
+                    if (d < d_end) {
+#pragma unroll
+                        for (int px = 0; px < NPIX; ++px) {
+                            if (h0 + jh0 + px * RP < p.oH && w0 + kw < p.oW) {
+                                if (in_yx[px] && z_ok) out[ooff[px] + dofs + i * ostride] = val[px];
+                                else if (!keep) out[ooff[px] + dofs + i * ostride] = 0.0f;
+                            }
+                        }
                     }
                 }
             }
+            slot_cur += G;
+            slot_cur = (slot_cur >= R) ? slot_cur - R : slot_cur;
         }
-        slot_cur += G;
-        slot_cur = (slot_cur >= R) ? slot_cur - R : slot_cur;
+    };
+    const int nit = (nvec + NT - 1) / NT;         // 1 .. kMaxIt
+    const bool fast = all_valid && (h0 + TH <= p.oH) && (w0 + TW <= p.oW) && ((d_end - d_begin) % G == 0);
+    using std::integral_constant;
+    if (fast) {
+        switch (nit) {
+            case 1: run(integral_constant<int, 1>{}, integral_constant<bool, true>{}); break;
+            case 2: run(integral_constant<int, 2>{}, integral_constant<bool, true>{}); break;
+            case 3: run(integral_constant<int, 3>{}, integral_constant<bool, true>{}); break;
+            default: run(integral_constant<int, 4>{}, integral_constant<bool, true>{}); break;
+        }
+    } else {
+        switch (nit) {
+            case 1: run(integral_constant<int, 1>{}, integral_constant<bool, false>{}); break;
+            case 2: run(integral_constant<int, 2>{}, integral_constant<bool, false>{}); break;
+            case 3: run(integral_constant<int, 3>{}, integral_constant<bool, false>{}); break;
+            default: run(integral_constant<int, 4>{}, integral_constant<bool, false>{}); break;
+        }
     }
 }
 
@@ -747,8 +794,8 @@ static const MarchCfg kMarch[] = {
     {16, 32, 2, 1, 256},   // 0: two pixels per thread, 128-byte store rows, shallow ring (most workgroups per CU)
     {8, 32, 2, 1, 256},    // 1: one pixel per thread, half the footprint
     {16, 64, 2, 1, 512},   // 2: 512 threads, 256-byte store rows (measured: no faster than 0)
-    {16, 32, 2, 2, 256},   // 3: deeper ring (experiments: never faster on MI355X)
-    {16, 32, 4, 1, 256},   // 4: fewer barriers
+    {16, 32, 2, 2, 256},   // 3: two groups in flight
+    {16, 32, 4, 1, 256},   // 4: four planes per barrier
     {32, 64, 2, 1, 1024},  // 5: 1024 threads
 };
 int march_config_count() { return (int)(sizeof(kMarch) / sizeof(kMarch[0])); }
