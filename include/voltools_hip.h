@@ -50,7 +50,9 @@ enum vt_flags {
     VT_FORCE_TILED = 8,    /* diagnostic: use the LDS-tiled kernel even for tiny volumes                    */
     VT_NO_ZSEP = 16,       /* diagnostic: disable the axis-0-separable kernels (use the general tiled kernel) */
     VT_NO_MARCH = 32,      /* diagnostic: axis-0-separable matrices use the 3-D tiled kernel, not the marching one */
-    VT_NO_ZPAIR = 64       /* diagnostic: cubic marching on the plain layout instead of the plane-pair copy          */
+    VT_NO_ZPAIR = 64,      /* diagnostic: cubic marching on the plain layout instead of the plane-pair copy          */
+    VT_NO_PACKED = 128,    /* diagnostic: general matrices use bounding-box tiles, not packed footprints             */
+    VT_FORCE_PACKED = 256  /* diagnostic: packed footprints whenever they fit, even where boxes are cheaper          */
 };
 
 /* flags for vt_volume_create* */
@@ -75,7 +77,7 @@ typedef struct vt_volume_info {
     int32_t interp;
     int32_t depth, height, width;      /* resident source dims (including any slab halo planes)            */
     int32_t out_depth, out_height, out_width;
-    int32_t last_kernel;               /* 0 none, 1 direct, 2 tiled, 3 tiled axis-0-separable, 4 marching, 5 marching on plane pairs */
+    int32_t last_kernel;               /* 0 none, 1 direct, 2 tiled (boxes), 3 tiled axis-0-separable, 4 marching, 5 marching on plane pairs, 6 tiled (packed footprints) */
     int32_t last_tile[3];              /* output tile (TD, TH, TW) of the last tiled launch (marching: G, TH, TW) */
     int32_t last_lds_dims[3];          /* staged source box (Lz, Ly, Lx) (marching: ring slots, Ly, Lx)    */
     int32_t last_lds_bytes;

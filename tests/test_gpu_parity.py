@@ -68,7 +68,8 @@ def test_tiled_and_direct_match_oracle(interp, mname, shape):
     want = oracle.affine(vol, m, interp)
     kernels = set()
     for flags in (_native.FORCE_TILED, _native.FORCE_TILED | _native.NO_ZPAIR, _native.FORCE_TILED | _native.NO_MARCH,
-                  _native.FORCE_TILED | _native.NO_ZSEP, _native.FORCE_DIRECT):
+                  _native.FORCE_TILED | _native.NO_ZSEP | _native.FORCE_PACKED, _native.FORCE_TILED | _native.NO_ZSEP | _native.NO_PACKED,
+                  _native.FORCE_DIRECT):
         got, info = run_case(vol, m, interp, flags)
         kernels.add(info.last_kernel)
         err = np.abs(got - want).max()
@@ -78,6 +79,8 @@ def test_tiled_and_direct_match_oracle(interp, mname, shape):
         assert (5 in kernels) == (interp != 'linear')   # cubic: the plane-pair marching kernel too
     if mname not in ('minify_big', 'far_outside'):
         assert 2 in kernels and 1 in kernels
+    if mname in ('rot_general', 'shear', 'rot_scale_shift', 'minify', 'mirror'):
+        assert 6 in kernels                          # packed-footprint kernel for invertible general matrices
 
 
 @pytest.mark.parametrize('interp', ['linear', 'bspline', 'filt_bspline'])
@@ -86,6 +89,9 @@ def test_default_dispatch_uses_tiled_kernel_on_large_volumes(interp):
     vol = rand_vol(shape, 2)
     m = MATRICES['rot_general'](shape)
     got, info = run_case(vol, m, interp)
+    assert info.last_kernel == 6 and info.last_lds_bytes > 0
+    assert np.abs(got - oracle.affine(vol, m, interp)).max() <= TOL[interp]
+    got, info = run_case(vol, m, interp, _native.NO_PACKED)
     assert info.last_kernel == 2 and info.last_lds_bytes > 0
     m = MATRICES['rot_inplane45'](shape)
     got, info = run_case(vol, m, interp)
@@ -102,7 +108,8 @@ def test_degenerate_and_ragged_shapes(shape, interp):
         m = MATRICES[mname](shape)
         want = oracle.affine(vol, m, interp)
         for flags in (_native.FORCE_TILED, _native.FORCE_TILED | _native.NO_ZPAIR, _native.FORCE_TILED | _native.NO_MARCH,
-                      _native.FORCE_TILED | _native.NO_ZSEP, _native.FORCE_DIRECT):
+                      _native.FORCE_TILED | _native.NO_ZSEP | _native.FORCE_PACKED, _native.FORCE_TILED | _native.NO_ZSEP | _native.NO_PACKED,
+                      _native.FORCE_DIRECT):
             got, _ = run_case(vol, m, interp, flags)
             assert np.abs(got - want).max() <= TOL[interp], (shape, interp, mname, flags)
 
@@ -277,10 +284,13 @@ def test_full_size_properties_512(interp):
     m = vt.utils.transform_matrix(rotation=(25, -40, 70), rotation_order='sxyz', center=centre((n, n, n)))
     sv.affine(m, output=out)
     a = out.get()
-    assert sv.info().last_kernel == 2
+    assert sv.info().last_kernel == 6
     sv.affine(m, output=out, _flags=_native.FORCE_DIRECT)
     b = out.get()
     assert np.abs(a - b).max() <= tol
+    sv.affine(m, output=out, _flags=_native.NO_PACKED)
+    assert sv.info().last_kernel == 2
+    assert np.abs(out.get() - b).max() <= tol
     # in-plane rotation: separable kernel vs general kernel vs direct kernel
     m = vt.utils.transform_matrix(rotation=(0, 33, 0), translation=(0.25, 1.5, -2.0), center=centre((n, n, n)))
     sv.affine(m, output=out)
@@ -294,6 +304,9 @@ def test_full_size_properties_512(interp):
     assert np.abs(a - out.get()).max() <= tol
     sv.affine(m, output=out, _flags=_native.NO_ZSEP)
     assert sv.info().last_kernel == 2
+    assert np.abs(a - out.get()).max() <= tol
+    sv.affine(m, output=out, _flags=_native.NO_ZSEP | _native.FORCE_PACKED)
+    assert sv.info().last_kernel == 6
     assert np.abs(a - out.get()).max() <= tol
     sv.affine(m, output=out, _flags=_native.FORCE_DIRECT)
     assert np.abs(a - out.get()).max() <= tol

@@ -16,6 +16,7 @@ ap.add_argument('--size', type=int, default=512)
 ap.add_argument('--interp', default='linear')
 ap.add_argument('--angle', type=float, default=45.0)
 ap.add_argument('--general', action='store_true', help='general 3-D rotation (25,-40,70) sxyz instead of in-plane')
+ap.add_argument('--case', default='', help='named matrix from tests/test_gpu_parity.py MATRICES (overrides --angle/--general)')
 ap.add_argument('--iters', type=int, default=10)
 ap.add_argument('--flags', type=int, default=0)
 args = ap.parse_args()
@@ -29,6 +30,11 @@ if args.general:
     m = vt.utils.transform_matrix(rotation=(25, -40, 70), rotation_order='sxyz', center=c)
 else:
     m = vt.utils.transform_matrix(rotation=(0, args.angle, 0), rotation_order='rzxz', center=c)
+if args.case:
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+    from test_gpu_parity import MATRICES
+    m = MATRICES[args.case]((n, n, n))
 for _ in range(3):
     sv.affine(m, output=out, _flags=args.flags)
 sv.synchronize()
@@ -37,6 +43,6 @@ for _ in range(args.iters):
     sv.affine(m, output=out, _flags=args.flags)
 ms = sv.timer_stop() / args.iters
 info = sv.info()
-print(f'{args.interp} {n}^3 angle={args.angle} general={args.general}: {ms:.4f} ms/launch, '
+print(f'{args.interp} {n}^3 angle={args.angle} general={args.general} case={args.case} kernel={info.last_kernel}: {ms:.4f} ms/launch, '
       f'{n ** 3 / ms / 1e6:.1f} Gvox/s, {8.0 * n ** 3 / ms / 1e6:.1f} GB/s algorithmic, tile={tuple(info.last_tile)} '
       f'box={tuple(info.last_lds_dims)} lds={info.last_lds_bytes} prefilter_ms={info.prefilter_ms:.3f}')

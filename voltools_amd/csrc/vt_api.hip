@@ -404,7 +404,7 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
             plan->kind = 1;
         }
     }
-    double best_cost = 1e300;
+    double best_cost = 1e300, box_bpv = 1e300;
     for (int c = 0; c < tile_config_count(); ++c) {
         if (v->force_cfg >= 0 && c != v->force_cfg) continue;
         int T[3];
@@ -429,9 +429,103 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
         double cost = (double)bytes / vox * (blocks_per_cu >= 3 ? 1.0 : (blocks_per_cu == 2 ? 1.25 : 2.0));
         if (cost < best_cost) {
             best_cost = cost;
+            box_bpv = (double)bytes / vox;
             plan->kind = zsep ? 3 : 2; plan->cfg = c; plan->td = T[0]; plan->th = T[1]; plan->tw = T[2];
             plan->lds_bytes = (int)bytes;
             p->Lz = L[0]; p->Ly = L[1]; p->Lx = L[2];
+        }
+    }
+    // general matrices: packed 3-D footprints (kind 6) when the linear part is invertible
+    // Bounding boxes are cheaper to address (no row table), so the packed form must stage clearly less to win:
+    // measured cross-over at ~0.6x (trilinear) / ~0.5x (cubic) of the box bytes per voxel (512^3).
+    if (!zsep && !(flags & VT_NO_PACKED)) {
+        const double A[9] = {m[0], m[1], m[2], m[4], m[5], m[6], m[8], m[9], m[10]};
+        const double det = A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6]) + A[2] * (A[3] * A[7] - A[4] * A[6]);
+        double amax = 0;
+        for (double a : A) amax = std::max(amax, std::fabs(a));
+        if (std::fabs(det) > 1e-6 * amax * amax * amax && amax < 64.0) {
+            const double id = 1.0 / det;
+            const double inv[9] = {(A[4] * A[8] - A[5] * A[7]) * id, (A[2] * A[7] - A[1] * A[8]) * id, (A[1] * A[5] - A[2] * A[4]) * id,
+                                   (A[5] * A[6] - A[3] * A[8]) * id, (A[0] * A[8] - A[2] * A[6]) * id, (A[2] * A[3] - A[0] * A[5]) * id,
+                                   (A[3] * A[7] - A[4] * A[6]) * id, (A[1] * A[6] - A[0] * A[7]) * id, (A[0] * A[4] - A[1] * A[3]) * id};
+            double best = 1e300, best_bpv = 1e300;
+            TilePlan pk = *plan;
+            AffineParams pp = *p;
+            pk.kind = 0;
+            for (int c = 0; c < packed_config_count(); ++c) {
+                if (v->force_cfg >= 0 && c != v->force_cfg) continue;
+                int T[3];
+                packed_config(c, &T[0], &T[1], &T[2]);
+                PackGeom g;
+                int L[3];
+                bool ok = true;
+                double neg[3], pos[3];
+                for (int r = 0; r < 3 && ok; ++r) {
+                    double ext = 0;
+                    neg[r] = pos[r] = 0;
+                    for (int k = 0; k < 3; ++k) {
+                        const double e = m[4 * r + k] * (T[k] - 1);
+                        ext += std::fabs(e);
+                        if (e < 0) neg[r] += e; else pos[r] += e;
+                    }
+                    if (!(ext < 1000.0)) { ok = false; break; }
+                    g.ext[r] = ext;
+                    L[r] = (int)std::floor(ext) + 3 + halo2;
+                }
+                if (!ok) continue;
+                L[2] = (L[2] + 3 + 3) & ~3;
+                const int rows = L[0] * L[1];
+                if (rows > packed_rows_max() || L[2] > 4000) continue;
+                for (int i = 0; i < 9; ++i) g.inv[i] = inv[i];
+                for (int cc = 0; cc < 3; ++cc) g.cst[cc] = inv[3 * cc] * neg[0] + inv[3 * cc + 1] * neg[1] + inv[3 * cc + 2] * neg[2];
+                g.T[0] = T[0]; g.T[1] = T[1]; g.T[2] = T[2];
+                g.halo = cubic ? 1 : 0;
+                g.Lxbox = L[2];
+                g.Lybox = L[1];
+                int nvec = 0;
+                for (int row = 0; row < rows; ++row) {
+                    int mn, mx;
+                    if (packed_row_span(g, row / L[1], row % L[1], &mn, &mx)) nvec += ((mx - (mn & ~3)) >> 2) + 1;
+                }
+                const int cap_vec = nvec + rows / 16 + 8;                 // margin for host/device rounding differences
+                if (cap_vec > packed_vectors_max()) continue;
+                const int table_floats = (2 * rows + 8 + 3) & ~3;
+                const int64_t bytes = ((int64_t)table_floats + (int64_t)cap_vec * 4) * 4;
+                if (bytes > v->lds_limit) continue;
+                const int blocks_per_cu = (int)std::min<int64_t>(cubic ? 2 : 3, (160 * 1024) / bytes);   // VGPR-limited occupancy
+                const double vox = (double)T[0] * T[1] * T[2];
+                const double cost = (double)bytes / vox * (blocks_per_cu >= 3 ? 1.0 : (blocks_per_cu == 2 ? 1.2 : 2.0));
+                if (cost < best) {
+                    best = cost;
+                    best_bpv = (double)bytes / vox;
+                    pk.kind = 6; pk.cfg = c; pk.td = T[0]; pk.th = T[1]; pk.tw = T[2];
+                    pk.lds_bytes = (int)bytes;
+                    pp.Lz = L[0]; pp.Ly = L[1]; pp.Lx = cap_vec * 4;
+                    pp.slot_floats = table_floats;
+                    for (int r = 0; r < 3; ++r) { pp.neg[r] = neg[r]; pp.pos[r] = pos[r]; }
+                    pk.geo = g;
+                    pk.blocks_per_cu = blocks_per_cu;
+                }
+            }
+            const bool forced = (flags & VT_FORCE_PACKED) != 0;
+            if (pk.kind == 6 && (plan->kind < 2 || forced || best_bpv < (cubic ? 0.5 : 0.6) * box_bpv)) {
+                *plan = pk;
+                *p = pp;
+                const int T[3] = {plan->td, plan->th, plan->tw};
+                p->nTd = (v->oD + T[0] - 1) / T[0];
+                p->nTh = (v->oH + T[1] - 1) / T[1];
+                p->nTw = (v->oW + T[2] - 1) / T[2];
+                const int64_t ntiles = (int64_t)p->nTd * p->nTh * p->nTw;
+                if (ntiles <= 0x7fffffffLL) {
+                    // persistent workgroups: as many as stay resident, a multiple of 8 (one share per XCD)
+                    int64_t nwg = std::min<int64_t>(ntiles, (int64_t)v->cu_count * std::max(1, plan->blocks_per_cu));
+                    nwg = std::max<int64_t>(8, (nwg + 7) / 8 * 8);
+                    plan->grid = (int)nwg;
+                    return 0;
+                }
+                plan->kind = 1;
+                return 0;
+            }
         }
     }
     if (plan->kind < 2) return 0;              // footprint does not fit LDS: direct gather
@@ -505,6 +599,12 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
         }
         VT_HIP(launch_affine_zpair(plan.cfg, v->interp, v->d_src_zp, d_out, p, plan.grid, plan.lds_bytes, v->stream));
         v->last_kernel = 5;
+        v->last_tile[0] = plan.td; v->last_tile[1] = plan.th; v->last_tile[2] = plan.tw;
+        v->last_lds[0] = p.Lz; v->last_lds[1] = p.Ly; v->last_lds[2] = p.Lx;
+        v->last_lds_bytes = plan.lds_bytes; v->last_grid = plan.grid;
+    } else if (plan.kind == 6) {
+        VT_HIP(launch_affine_packed(plan.cfg, v->interp, v->d_src, d_out, v->d_zeros, p, plan.geo, plan.grid, plan.lds_bytes, v->stream));
+        v->last_kernel = 6;
         v->last_tile[0] = plan.td; v->last_tile[1] = plan.th; v->last_tile[2] = plan.tw;
         v->last_lds[0] = p.Lz; v->last_lds[1] = p.Ly; v->last_lds[2] = p.Lx;
         v->last_lds_bytes = plan.lds_bytes; v->last_grid = plan.grid;

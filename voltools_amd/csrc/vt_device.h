@@ -56,6 +56,30 @@ __device__ __forceinline__ int xcd_contiguous(int b, int n)
 }
 
 
+// Q32.32 fixed-point coordinate: hi = integer part (box index), lo = fraction.  Stepping along the tile's
+// depth axis is two full-rate integer adds per axis instead of float64 arithmetic; the split into
+// (index, fraction) is free.  For ordinary matrices (float32 entries of moderate magnitude) the arithmetic
+// is exact; otherwise the drift is < 2^-29 voxel over a tile column.
+struct Fx { int hi; unsigned lo; };
+
+__device__ __forceinline__ Fx to_fx(double x)
+{
+    const double fl = floor(x);
+    Fx r;
+    r.hi = (int)fl;
+    r.lo = (unsigned)((x - fl) * 4294967296.0);
+    return r;
+}
+
+__device__ __forceinline__ void fx_step(Fx& c, int inc_hi, unsigned inc_lo)
+{
+    const unsigned lo = c.lo + inc_lo;
+    c.hi += inc_hi + (lo < c.lo ? 1 : 0);
+    c.lo = lo;
+}
+
+__device__ __forceinline__ float fx_frac(const Fx& c) { return (float)c.lo * 0x1p-32f; }
+
 // ---------------------------------------------------------------------------------------------------
 // direct (untiled) sampling from global memory with explicit border tests
 // ---------------------------------------------------------------------------------------------------

@@ -38,13 +38,6 @@ struct AffineParams {
     int32_t zero_off2;         // plane-pair layout: byte offset of a zero vector inside any pair-plane
 };
 
-struct TilePlan {
-    int kind;            // 1 direct, 2 tiled, 3 tiled axis-0-separable, 4 marching axis-0-separable, 5 marching on plane pairs
-    int cfg;             // index into the tile table
-    int td, th, tw;
-    int lds_bytes;
-    int grid;
-};
 
 // Columns [*mn, *mx] (box-relative) that the pixels of a TH x TW in-plane tile tap in box row Y, for the in-plane map
 // sy = by + a1*j + b1*k, sx = bx + a2*j + b2*k.  A pixel taps the row iff sy lies in [Y-1-halo, Y+halo+1); over the
@@ -98,6 +91,68 @@ __host__ __device__ inline bool march_row_span(double a1, double b1, double a2, 
     return true;
 }
 
+// Geometry of a tile's source footprint for the packed general-matrix kernel: u' = A.p - neg is the position of tile
+// voxel p inside the footprint's bounding box (before the sub-voxel offset of the tile is added).
+struct PackGeom {
+    double inv[9];     // A^-1 (rows: tile axes d,h,w; columns: source axes z,y,x)
+    double cst[3];     // A^-1 . neg
+    double ext[3];     // bounding-box extent of A.[0,T-1]^3 per source axis
+    int32_t T[3];      // tile dims
+    int32_t halo;      // 0 linear, 1 cubic
+    int32_t Lxbox;     // bounding-box row length (floats) incl. alignment slack
+    int32_t Lybox;
+};
+
+struct TilePlan {
+    int kind;            // 1 direct, 2 tiled, 3 tiled axis-0-separable, 4 marching, 5 marching on plane pairs, 6 tiled with packed footprints
+    int cfg;             // index into the tile table
+    int td, th, tw;
+    int lds_bytes;
+    int grid;
+    int blocks_per_cu;
+    PackGeom geo;       // kind 6 only
+};
+
+// Columns [*mn, *mx] (box-relative) that tile voxels can tap in box row (Z, Y), for EVERY sub-voxel position of a tile:
+// box coordinate = b + u' with b_z, b_y in [halo, halo+1), b_x in [halo, halo+4) (16-byte alignment of the box origin).
+// Row Z is tapped iff u'_z in (Z-2-2*halo, Z+1), same for Y.  Each pair of opposite faces of the tile bounds u'_x by an
+// interval that is linear in (u'_z, u'_y); over the rectangle of admissible (u'_z, u'_y) the lower end of the feasible u'_x
+// is >= max over faces of (min over the 4 corners), the upper end <= min over faces of (max over corners).
+// Conservative (a superset of the taps), cheap (3 x 4 corner evaluations), identical on host and device.
+__host__ __device__ inline bool packed_row_span(const PackGeom& g, int Z, int Y, int* mn, int* mx)
+{
+    const double zlo = (double)(Z - 2 - 2 * g.halo) - 1e-6, zhi = (double)(Z + 1) + 1e-6;
+    const double ylo = (double)(Y - 2 - 2 * g.halo) - 1e-6, yhi = (double)(Y + 1) + 1e-6;
+    // rows the footprint cannot reach at all
+    if (zhi < 0.0 || zlo > g.ext[0] || yhi < 0.0 || ylo > g.ext[1]) { *mn = 0; *mx = -1; return false; }
+    double LB = 0.0, UB = g.ext[2];
+    for (int c = 0; c < 3; ++c) {
+        const double gz = g.inv[3 * c], gy = g.inv[3 * c + 1], gx = g.inv[3 * c + 2];
+        if (gx > -1e-9 && gx < 1e-9) continue;                  // this pair of faces does not bound x
+        const double inv_gx = 1.0 / gx;
+        const double top = (double)(g.T[c] - 1);
+        double lo_min = 1e30, hi_max = -1e30;
+        for (int k = 0; k < 4; ++k) {
+            const double uz = (k & 1) ? zhi : zlo, uy = (k & 2) ? yhi : ylo;
+            const double s = gz * uz + gy * uy + g.cst[c];
+            const double xa = (0.0 - s) * inv_gx, xb = (top - s) * inv_gx;
+            const double lo = xa < xb ? xa : xb, hi = xa < xb ? xb : xa;
+            lo_min = lo < lo_min ? lo : lo_min;
+            hi_max = hi > hi_max ? hi : hi_max;
+        }
+        LB = lo_min > LB ? lo_min : LB;
+        UB = hi_max < UB ? hi_max : UB;
+    }
+    if (LB > UB + 1e-6) { *mn = 0; *mx = -1; return false; }
+    int a = (int)floor(LB - 1e-6);                               // + b_x (>= halo) - halo taps
+    int b = (int)floor(UB + 1e-6 + (double)g.halo + 4.0) + 1 + g.halo;
+    if (a < 0) a = 0;
+    if (b > g.Lxbox - 1) b = g.Lxbox - 1;
+    *mn = a;
+    *mx = b;
+    return a <= b;
+}
+
 // launchers (vt_kernels_affine.hip)
 int tile_config_count();
 void tile_config(int idx, int* td, int* th, int* tw);
@@ -110,6 +165,13 @@ void zpair_config(int idx, int* th, int* tw, int* la, int* nt);
 hipError_t launch_affine_zpair(int cfg, int interp, const float* src2, float* out, const AffineParams& p,
                                int grid, int lds_bytes, hipStream_t stream);
 hipError_t launch_relayout_zpair(const float* src, float* dst, int D, int H, int W, int P, int P2, hipStream_t stream);
+int packed_config_count();
+void packed_config(int idx, int* td, int* th, int* tw);
+int packed_rows_max();
+int packed_vectors_max();
+hipError_t init_packed_kernels();
+hipError_t launch_affine_packed(int cfg, int interp, const float* src, float* out, const float* zeros16,
+                                const AffineParams& p, const PackGeom& geo, int grid, int lds_bytes, hipStream_t stream);
 int march_rows_max();
 int march_max_it();
 int interp_kind(int interp);

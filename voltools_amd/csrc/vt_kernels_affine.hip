@@ -100,30 +100,6 @@ __device__ __forceinline__ float sample_box(const float* __restrict__ lds, int L
     }
 }
 
-// Q32.32 fixed-point coordinate: hi = integer part (box index), lo = fraction.  Stepping along the tile's
-// depth axis is two full-rate integer adds per axis instead of float64 arithmetic; the split into
-// (index, fraction) is free.  For ordinary matrices (float32 entries of moderate magnitude) the arithmetic
-// is exact; otherwise the drift is < 2^-29 voxel over a tile column.
-struct Fx { int hi; unsigned lo; };
-
-__device__ __forceinline__ Fx to_fx(double x)
-{
-    const double fl = floor(x);
-    Fx r;
-    r.hi = (int)fl;
-    r.lo = (unsigned)((x - fl) * 4294967296.0);
-    return r;
-}
-
-__device__ __forceinline__ void fx_step(Fx& c, int inc_hi, unsigned inc_lo)
-{
-    const unsigned lo = c.lo + inc_lo;
-    c.hi += inc_hi + (lo < c.lo ? 1 : 0);
-    c.lo = lo;
-}
-
-__device__ __forceinline__ float fx_frac(const Fx& c) { return (float)c.lo * 0x1p-32f; }
-
 template <int KIND /*0 linear, 1 cubic (bspline_weights), 2 cubic (bspline fn)*/, int TD, int TH, int TW>
 __global__ __launch_bounds__(256) void affine_tiled(const float* __restrict__ src, float* __restrict__ out,
                                                      const float* __restrict__ zeros16, const AffineParams p)

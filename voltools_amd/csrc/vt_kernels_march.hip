@@ -862,6 +862,10 @@ hipError_t launch_affine_zpair(int cfg, int interp, const float* src2, float* ou
 
 hipError_t init_march_kernels()
 {
+    {
+        hipError_t e = init_packed_kernels();
+        if (e != hipSuccess) return e;
+    }
     for (int cfg = 0; cfg < zpair_config_count(); ++cfg)
         for (int kind = 1; kind < 3; ++kind) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(zpair_entry(cfg, kind)),

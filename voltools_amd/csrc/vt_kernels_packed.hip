@@ -1,0 +1,331 @@
+// vt_kernels_packed.hip -- general-matrix transform kernel with packed 3-D footprints (gfx950).
+//
+// `affine_tiled` (vt_kernels_affine.hip) stages the axis-aligned bounding box of a tile's source footprint.  For a general
+// 3-D rotation of a 16^3 tile that box is 27 x 28 x 32 floats (97 KB: one workgroup per CU, 5.4x the tile's volume).
+// Here only the footprint itself is staged:
+//   * the footprint of a TD x TH x TW tile is the parallelepiped A.[0,T-1]^3 (+ the interpolation taps); for every
+//     (z, y) row of its bounding box the workgroup computes -- once, analytically -- the x-span the parallelepiped can
+//     reach in that row (valid for every sub-voxel position of a tile, so one table serves all tiles of the launch),
+//     aligns it to 16 bytes and packs the spans back to back (block-wide prefix sum);
+//   * every thread derives once the source offsets of the 16-byte vectors it stages per tile and keeps them in registers;
+//     workgroups are persistent and walk tiles in an XCD-contiguous order, so this set-up is amortised over many tiles;
+//   * per tile: `global_load_lds` of the packed footprint (border vectors from a block of zeros), one barrier, gather.
+//     The gather finds a tap row's LDS position through the row table (2 extra LDS reads per voxel for trilinear).
+// LDS per workgroup drops ~3x (more workgroups per CU) and so does the L2 -> LDS traffic.
+// Coordinates: Q32.32 fixed-point stepping along the tile depth exactly as in affine_tiled.
+#include "vt_internal.h"
+#include "vt_device.h"
+
+namespace vt {
+
+constexpr int kPackMaxIt = 16;        // <= 4096 vectors (64 KiB) per tile footprint
+constexpr int kPackRowsMax = 1024;    // (z, y) rows of the bounding box
+
+// 16 bytes per lane, global memory -> LDS at lds_addr + 16 * lane, without a register round trip.
+// Written as inline assembly: with the builtin, hipcc 7.2 merges the M0 initialisations of an unrolled sequence of
+// direct-to-LDS loads and every load lands on the first destination.  The caller waits with s_waitcnt vmcnt(0).
+__device__ __forceinline__ void lds_dma16(const float* g, unsigned lds_addr)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_addr) : "memory", "m0");
+}
+
+template <int KIND, int TD, int TH, int TW>
+__global__ __launch_bounds__(256) void affine_tiled_packed(const float* __restrict__ src, float* __restrict__ out,
+                                                            const float* __restrict__ zeros16, const AffineParams p,
+                                                            const PackGeom geo)
+{
+    static_assert(256 % TW == 0 && TH % (256 / TW) == 0, "tile/thread mapping");
+    constexpr bool CUBIC = KIND != 0;
+    constexpr int HALO = CUBIC ? 1 : 0;
+    constexpr int RP = 256 / TW;
+    constexpr int NJ = TH / RP;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int Lz = p.Lz, Ly = p.Ly;
+    const int rows = Lz * Ly;                       // <= kPackRowsMax (host-checked)
+    // LDS: [rowbase: rows ints][x0: rows ints][scratch 8 ints] | footprint buffer
+    int* rowbase = reinterpret_cast<int*>(lds);
+    int* rowx0 = rowbase + rows;
+    int* scratch = rowx0 + rows;
+    float* buf = lds + p.slot_floats;               // slot_floats = table size in floats (multiple of 4)
+
+    // ---- row spans + block-wide exclusive prefix sum (4 rows per thread) ----
+    int nv[4], x0s[4];
+    int local = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = tid * 4 + r;
+        int mn = 0, mx = -1;
+        const bool used = (row < rows) && packed_row_span(geo, row / Ly, row % Ly, &mn, &mx);
+        x0s[r] = used ? (mn & ~3) : 0;
+        nv[r] = used ? (((mx - x0s[r]) >> 2) + 1) : 0;
+        local += nv[r];
+    }
+    int incl = local;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const int up = __shfl_up(incl, s);
+        if (lane >= s) incl += up;
+    }
+    if (lane == 63) scratch[wave] = incl;
+    __syncthreads();
+    int wave_off = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) wave_off += (w < wave) ? scratch[w] : 0;
+    const int nvec = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+    int run = wave_off + incl - local;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = tid * 4 + r;
+        if (row < rows) { rowbase[row] = run; rowx0[row] = x0s[r]; }      // rowbase holds the first vector for now
+        run += nv[r];
+    }
+    __syncthreads();
+
+    const int ntiles = p.nTd * p.nTh * p.nTw;
+    const bool keep = (p.flags & VT_KEEP_OUTSIDE) != 0;
+    const int64_t ostride = (int64_t)p.oH * p.oW;
+    const int kw = tid % TW;
+    const int jh0 = tid / TW;
+    const bool fits = (nvec * 4 <= p.Lx) && (nvec <= 256 * kPackMaxIt);  // p.Lx = footprint buffer capacity in floats
+
+    // staging descriptors: element offset relative to the box origin, and the packed (z, y, x) of the vector
+    int rel[kPackMaxIt], zyx[kPackMaxIt];
+    if (fits) {
+#pragma unroll
+        for (int it = 0; it < kPackMaxIt; ++it) {
+            const int v = tid + 256 * it;
+            int row = 0;
+            if (v < nvec) {
+                int a = 0, b = rows - 1;            // largest row whose first vector is <= v
+                while (a < b) {
+                    const int mid = (a + b + 1) >> 1;
+                    if (rowbase[mid] <= v) a = mid; else b = mid - 1;
+                }
+                row = a;
+            }
+            const int Z = row / Ly, Y = row - Z * Ly;
+            const int xv = rowx0[row] + 4 * (v - rowbase[row]);
+            rel[it] = (Z * p.sH + Y) * p.sP + xv;
+            zyx[it] = (Z << 22) | (Y << 12) | (xv & 0xfff);
+        }
+    }
+    __syncthreads();
+    // turn the table into what the gather needs: LDS float offset of column 0 of every row
+    for (int row = tid; row < rows; row += 256) rowbase[row] = 4 * rowbase[row] - rowx0[row];
+    __syncthreads();
+
+    // ---- persistent loop over tiles (XCD-contiguous order) ----
+    // Virtual block vb = blockIdx.x + k * gridDim.x plays the role of block vb of a launch with `ntiles` blocks: gridDim.x
+    // is a multiple of 8, so vb lands on the same XCD as this workgroup and xcd_contiguous() keeps every XCD on a
+    // contiguous range of tiles.
+    const int nwg = gridDim.x;
+    for (int vb = blockIdx.x; vb < ntiles; vb += nwg) {
+        const int t = xcd_contiguous(vb, ntiles);
+        const int tw_i = t % p.nTw;
+        const int t2 = t / p.nTw;
+        const int th_i = t2 % p.nTh;
+        const int td_i = t2 / p.nTh;
+        const int d0 = td_i * TD, h0 = th_i * TH, w0 = tw_i * TW;
+        const int nd = min(TD, p.oD - d0);
+
+        double base[3], lo[3], hi[3];
+        bool any_valid = true, all_valid = true;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            base[r] = fma(p.m[4 * r], (double)d0, fma(p.m[4 * r + 1], (double)h0, fma(p.m[4 * r + 2], (double)w0, p.m[4 * r + 3])));
+            lo[r] = base[r] + p.neg[r];
+            hi[r] = base[r] + p.pos[r];
+            any_valid = any_valid && (hi[r] >= p.vlo[r]) && (lo[r] < p.vhi[r]);
+            all_valid = all_valid && (lo[r] >= p.vlo[r]) && (hi[r] < p.vhi[r]);
+        }
+        if (!any_valid) {
+            if (!keep) {
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) {
+                    const int h = h0 + jh0 + jj * RP, w = w0 + kw;
+                    if (h < p.oH && w < p.oW) {
+                        float* optr = out + ((int64_t)d0 * p.oH + h) * p.oW + w;
+                        for (int i = 0; i < nd; ++i) optr[i * ostride] = 0.0f;
+                    }
+                }
+            }
+        } else {
+            int o[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) o[r] = (int)floor(lo[r]) - HALO;
+            o[2] &= ~3;
+            double b[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) b[r] = base[r] - (double)o[r];
+
+            if (fits) {
+                // stage the packed footprint
+                const bool box_inside = o[0] >= 0 && o[1] >= 0 && o[2] >= 0 && o[0] + Lz <= p.sD && o[1] + Ly <= p.sH &&
+                                        o[2] + geo.Lxbox <= p.sP;
+                const int64_t origin = ((int64_t)o[0] * p.sH + o[1]) * p.sP + o[2];
+                const int wave_first = __builtin_amdgcn_readfirstlane(tid & ~63);
+                const unsigned buf_addr = __builtin_amdgcn_readfirstlane(
+                    (unsigned)(size_t)(__attribute__((address_space(3))) void*)buf);
+#pragma unroll
+                for (int it = 0; it < kPackMaxIt; ++it) {
+                    const int v0 = wave_first + 256 * it;
+                    if (v0 < nvec) {                              // wave-uniform
+                        const float* g = src + origin + rel[it];
+                        if (!box_inside) {
+                            const int gz = o[0] + (zyx[it] >> 22), gy = o[1] + ((zyx[it] >> 12) & 0x3ff), gx = o[2] + (zyx[it] & 0xfff);
+                            const bool inb = (unsigned)gz < (unsigned)p.sD && (unsigned)gy < (unsigned)p.sH && (unsigned)gx < (unsigned)p.sP;
+                            g = inb ? g : zeros16;
+                        }
+                        if (tid + 256 * it < nvec) lds_dma16(g, buf_addr + 16u * (unsigned)v0);
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the direct-to-LDS loads are invisible to hipcc's counters
+                __syncthreads();                                  // drains the direct-to-LDS loads
+
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) {
+                    const int j = jh0 + jj * RP;
+                    const int h = h0 + j, w = w0 + kw;
+                    if (h >= p.oH || w >= p.oW) continue;
+                    const double s0 = fma(p.m[1], (double)j, fma(p.m[2], (double)kw, b[0]));
+                    const double s1 = fma(p.m[5], (double)j, fma(p.m[6], (double)kw, b[1]));
+                    const double s2 = fma(p.m[9], (double)j, fma(p.m[10], (double)kw, b[2]));
+                    Fx c0 = to_fx(s0), c1 = to_fx(s1), c2 = to_fx(s2);
+                    double e0 = s0, e1 = s1, e2 = s2;
+                    const double vlo0 = p.vlo[0] - (double)o[0], vhi0 = p.vhi[0] - (double)o[0];
+                    const double vlo1 = p.vlo[1] - (double)o[1], vhi1 = p.vhi[1] - (double)o[1];
+                    const double vlo2 = p.vlo[2] - (double)o[2], vhi2 = p.vhi[2] - (double)o[2];
+                    float* optr = out + ((int64_t)d0 * p.oH + h) * p.oW + w;
+                    for (int i = 0; i < nd; ++i) {
+                        const int iz = c0.hi, iy = c1.hi, ix = c2.hi;
+                        const float fz = fx_frac(c0), fy = fx_frac(c1), fx = fx_frac(c2);
+                        float val;
+                        if constexpr (!CUBIC) {
+                            const int* tr = rowbase + (__mul24(iz, Ly) + iy);
+                            const float* r00 = buf + tr[0] + ix;
+                            const float* r01 = buf + tr[1] + ix;
+                            const float* r10 = buf + tr[Ly] + ix;
+                            const float* r11 = buf + tr[Ly + 1] + ix;
+                            const float x00 = fmaf(fx, r00[1] - r00[0], r00[0]);
+                            const float x01 = fmaf(fx, r01[1] - r01[0], r01[0]);
+                            const float x10 = fmaf(fx, r10[1] - r10[0], r10[0]);
+                            const float x11 = fmaf(fx, r11[1] - r11[0], r11[0]);
+                            const float y0 = fmaf(fy, x01 - x00, x00);
+                            const float y1 = fmaf(fy, x11 - x10, x10);
+                            val = fmaf(fz, y1 - y0, y0);
+                        } else {
+                            float wx[4], wy[4], wz[4];
+                            cubic_weights<KIND == 2>(fx, wx);
+                            cubic_weights<KIND == 2>(fy, wy);
+                            cubic_weights<KIND == 2>(fz, wz);
+                            const int* tr = rowbase + (__mul24(iz - 1, Ly) + (iy - 1));
+                            val = 0.f;
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                float accy = 0.f;
+#pragma unroll
+                                for (int bb = 0; bb < 4; ++bb) {
+                                    const float* rowp = buf + tr[c * Ly + bb] + (ix - 1);
+                                    float accx = wx[0] * rowp[0];
+                                    accx = fmaf(wx[1], rowp[1], accx);
+                                    accx = fmaf(wx[2], rowp[2], accx);
+                                    accx = fmaf(wx[3], rowp[3], accx);
+                                    accy = fmaf(wy[bb], accx, accy);
+                                }
+                                val = fmaf(wz[c], accy, val);
+                            }
+                        }
+                        const bool inside = all_valid || ((e0 >= vlo0) && (e0 < vhi0) && (e1 >= vlo1) && (e1 < vhi1) && (e2 >= vlo2) && (e2 < vhi2));
+                        if (inside) optr[i * ostride] = val;
+                        else if (!keep) optr[i * ostride] = 0.0f;
+                        fx_step(c0, p.inc_hi[0], p.inc_lo[0]);
+                        fx_step(c1, p.inc_hi[1], p.inc_lo[1]);
+                        fx_step(c2, p.inc_hi[2], p.inc_lo[2]);
+                        e0 += p.m[0]; e1 += p.m[4]; e2 += p.m[8];
+                    }
+                }
+                __syncthreads();                                  // the buffer is restaged by the next tile
+            } else {
+                // the packed footprint does not fit the buffer planned on the host: gather from global memory
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) {
+                    const int j = jh0 + jj * RP;
+                    const int h = h0 + j, w = w0 + kw;
+                    if (h >= p.oH || w >= p.oW) continue;
+                    for (int i = 0; i < nd; ++i) {
+                        const int d = d0 + i;
+                        double s[3];
+                        bool inside = true;
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) {
+                            s[r] = fma(p.m[4 * r], (double)d, fma(p.m[4 * r + 1], (double)h, fma(p.m[4 * r + 2], (double)w, p.m[4 * r + 3])));
+                            inside = inside && (s[r] >= p.vlo[r]) && (s[r] < p.vhi[r]);
+                        }
+                        float* optr = out + ((int64_t)d * p.oH + h) * p.oW + w;
+                        if (inside) {
+                            const double fzd = floor(s[0]), fyd = floor(s[1]), fxd = floor(s[2]);
+                            *optr = direct_sample<KIND>(src, p, (int)fzd, (int)fyd, (int)fxd, (float)(s[0] - fzd), (float)(s[1] - fyd), (float)(s[2] - fxd));
+                        } else if (!keep) *optr = 0.0f;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+typedef void (*packed_fn)(const float*, float*, const float*, const AffineParams, const PackGeom);
+struct PackCfg { int td, th, tw; };
+static const PackCfg kPack[] = {
+    {8, 16, 32},
+    {16, 16, 16},
+    {8, 8, 32},
+};
+int packed_config_count() { return (int)(sizeof(kPack) / sizeof(kPack[0])); }
+void packed_config(int idx, int* td, int* th, int* tw) { *td = kPack[idx].td; *th = kPack[idx].th; *tw = kPack[idx].tw; }
+int packed_rows_max() { return kPackRowsMax; }
+int packed_vectors_max() { return 256 * kPackMaxIt; }
+
+template <int TD, int TH, int TW>
+static packed_fn pick_packed(int kind)
+{
+    switch (kind) {
+        case 0: return affine_tiled_packed<0, TD, TH, TW>;
+        case 1: return affine_tiled_packed<1, TD, TH, TW>;
+        default: return affine_tiled_packed<2, TD, TH, TW>;
+    }
+}
+static packed_fn packed_entry(int cfg, int kind)
+{
+    switch (cfg) {
+        case 0: return pick_packed<8, 16, 32>(kind);
+        case 1: return pick_packed<16, 16, 16>(kind);
+        default: return pick_packed<8, 8, 32>(kind);
+    }
+}
+
+hipError_t init_packed_kernels()
+{
+    for (int cfg = 0; cfg < packed_config_count(); ++cfg)
+        for (int kind = 0; kind < 3; ++kind) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(packed_entry(cfg, kind)),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+        }
+    return hipSuccess;
+}
+
+hipError_t launch_affine_packed(int cfg, int interp, const float* src, float* out, const float* zeros16,
+                                const AffineParams& p, const PackGeom& geo, int grid, int lds_bytes, hipStream_t stream)
+{
+    packed_fn fn = packed_entry(cfg, interp_kind(interp));
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds_bytes, stream, src, out, zeros16, p, geo);
+    return hipGetLastError();
+}
+
+}  // namespace vt
