@@ -84,6 +84,7 @@ struct vt_volume {
     // last launch, for vt_volume_info
     int last_kernel = 0, last_tile[3] = {0, 0, 0}, last_lds[3] = {0, 0, 0}, last_lds_bytes = 0, last_grid = 0;
     int force_cfg = -1;                // VT_TILE environment override (experiments)
+    int force_la = 0;                  // VT_LA: groups staged ahead by the marching kernel (experiments)
 };
 
 namespace {
@@ -165,6 +166,7 @@ double gather_conflict_factor(double a, double b, int Lx, int ndw = 2)
 int estimate_packed_vectors(const double m[12], int th, int tw, int halo, int* rows_out)
 {
     const double a1 = m[5], b1 = m[6], a2 = m[9], b2 = m[10];       // d(sy)/dj, d(sy)/dk, d(sx)/dj, d(sx)/dk
+    const double ia1 = march_recip(a1), ib1 = march_recip(b1);
     double neg1 = 0, neg2 = 0;
     for (double e : {a1 * (th - 1), b1 * (tw - 1)}) if (e < 0) neg1 += e;
     for (double e : {a2 * (th - 1), b2 * (tw - 1)}) if (e < 0) neg2 += e;
@@ -177,7 +179,7 @@ int estimate_packed_vectors(const double m[12], int th, int tw, int halo, int* r
             int total = 0, rows = 0;
             for (int Y = 0; Y < 256; ++Y) {
                 int mn, mx;
-                if (!march_row_span(a1, b1, a2, b2, by, bx, Y, th, tw, halo, &mn, &mx)) continue;
+                if (!march_row_span(a1, b1, a2, b2, ia1, ib1, by, bx, Y, th, tw, halo, &mn, &mx)) continue;
                 total += ((mx - mn) >> 2) + 2;                   // +1 vector: unknown 16-byte phase of the span start
                 rows = Y + 1;
             }
@@ -204,6 +206,7 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
         if ((step - fl) * 4294967296.0 + 0.5 >= 4294967296.0) { p->inc_lo[r] = 0; p->inc_hi[r] += 1; }
     }
     p->oD = v->oD; p->oH = v->oH; p->oW = v->oW;
+    p->ia1 = march_recip(m[5]); p->ib1 = march_recip(m[6]);
     p->flags = (flags & VT_KEEP_OUTSIDE);
     // skirt rule src + 0.5 in [0, dim) on the global volume, expressed on resident coordinates
     p->vlo[0] = -0.5 - (double)v->plane0;  p->vhi[0] = (double)v->gD - 0.5 - (double)v->plane0;
@@ -268,7 +271,7 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
                     slot_floats = vecs * 4;
                     if (vecs > vec_max) continue;
                 } else if (L[1] * (L[2] / 2) > vec_max) continue;
-                const int64_t bytes = (int64_t)(la + 1) * slot_floats * 4;
+                const int64_t bytes = std::max<int64_t>((int64_t)(la + 1) * slot_floats * 4, zp_box ? 0 : march_table_bytes());
                 if (bytes > v->lds_limit) continue;
                 plan->kind = 5; plan->cfg = c; plan->td = 2; plan->th = th; plan->tw = tw;
                 plan->lds_bytes = (int)bytes;
@@ -318,6 +321,7 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
             if (v->force_cfg >= 0 && c != v->force_cfg) continue;
             int th, tw, g, la, nt;
             march_config(c, &th, &tw, &g, &la, &nt);
+            if (v->force_la > 0) la = v->force_la;
             const int vec_max = nt * march_max_it();
             const int T[3] = {1, th, tw};
             int L[3] = {0, 0, 0};
@@ -348,7 +352,7 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
                 if (L[1] * L[2] / 4 > vec_max) continue;
             }
             const int ring = (la + 1) * g + halo2 + 1;
-            const int64_t bytes = std::max<int64_t>((int64_t)ring * slot_floats * 4, 1024);
+            const int64_t bytes = std::max<int64_t>((int64_t)ring * slot_floats * 4, march_box ? 1024 : march_table_bytes());
             if (bytes > v->lds_limit) continue;
             const int blocks_per_cu = (int)std::min<int64_t>(8, (160 * 1024) / bytes);
             // measured on MI355X (512^3 and 1024^3, 0..45 degrees): resident workgroups per CU matter more than
@@ -656,6 +660,7 @@ int create_common(int dev, int D, int H, int W, int interp, const float* data, i
     v->oD = oD; v->oH = H; v->oW = W;
     v->plane0 = plane0; v->gD = gD; v->out_plane0 = out_plane0;
     if (const char* t = std::getenv("VT_TILE")) v->force_cfg = std::atoi(t);
+    if (const char* t = std::getenv("VT_LA")) v->force_la = std::atoi(t);
 
     auto cleanup = [&](int code) {
         vt_volume_destroy(v);

@@ -36,6 +36,7 @@ struct AffineParams {
     int32_t slot_floats;       // marching kernel: floats per LDS plane slot (packed footprint, multiple of 4)
     int32_t sP2;               // plane-pair layout: floats per pair-row (2 * (roundup4(W) + 4))
     int32_t zero_off2;         // plane-pair layout: byte offset of a zero vector inside any pair-plane
+    double ia1, ib1;           // marching kernels: march_recip(m[1][1]), march_recip(m[1][2])
 };
 
 
@@ -45,8 +46,11 @@ struct AffineParams {
 // corner inside the strip, or a point where a strip line crosses a rectangle edge.  The result is a superset of the
 // taps of the discrete pixels (widened by 1e-6).  Shared by the marching kernel (per workgroup) and the host planner
 // (slot sizing), so both see the same spans.  Returns false when no pixel taps the row.
-__host__ __device__ inline bool march_row_span(double a1, double b1, double a2, double b2, double by, double bx,
-                                               int Y, int TH, int TW, int halo, int* mn, int* mx)
+// ia1 / ib1: reciprocals of a1 / b1, 0 where the coefficient vanishes (march_recip; wave-uniform, computed on the host).
+__host__ __device__ inline double march_recip(double a) { return (a > 1e-12 || a < -1e-12) ? 1.0 / a : 0.0; }
+
+__host__ __device__ inline bool march_row_span(double a1, double b1, double a2, double b2, double ia1, double ib1,
+                                               double by, double bx, int Y, int TH, int TW, int halo, int* mn, int* mx)
 {
     const double ylo = (double)(Y - 1 - halo), yhi = (double)(Y + halo + 1);
     const double jm = (double)(TH - 1), km = (double)(TW - 1);
@@ -61,7 +65,6 @@ __host__ __device__ inline bool march_row_span(double a1, double b1, double a2, 
                 smax = sx > smax ? sx : smax;
             }
         }
-    const double ia1 = (a1 > 1e-12 || a1 < -1e-12) ? 1.0 / a1 : 0.0, ib1 = (b1 > 1e-12 || b1 < -1e-12) ? 1.0 / b1 : 0.0;
     for (int e = 0; e < 2; ++e) {
         const double L = e ? yhi : ylo;
         for (int c = 0; c < 2; ++c) {
@@ -158,6 +161,7 @@ int tile_config_count();
 void tile_config(int idx, int* td, int* th, int* tw);
 hipError_t launch_affine_tiled(int cfg, int interp, bool zsep, const float* src, float* out, const float* zeros16,
                                const AffineParams& p, int grid, int lds_bytes, hipStream_t stream);
+int march_table_bytes();   // LDS bytes the packed-span set-up table needs (overlays the ring)
 int march_config_count();
 void march_config(int idx, int* th, int* tw, int* g, int* la, int* nt);
 int zpair_config_count();

@@ -75,8 +75,52 @@ __device__ __forceinline__ float plane_partial_rows(const float* __restrict__ pl
     }
 }
 
+// Register budget of the pair kernel: 4 waves per SIMD (128 VGPRs; the natural allocation is 138 -> 3 waves).
+#ifndef VT_ZPAIR_WAVES
+#define VT_ZPAIR_WAVES 4
+#endif
+#if VT_ZPAIR_WAVES > 0
+#define VT_ZPAIR_OCC __attribute__((amdgpu_waves_per_eu(VT_ZPAIR_WAVES, VT_ZPAIR_WAVES)))
+#else
+#define VT_ZPAIR_OCC
+#endif
+
 constexpr int kRowsMax = 64;      // source rows a tile's footprint may span (host-checked)
 constexpr int kMaxIt = 4;         // packed footprint <= 1024 vectors (16 KiB) per plane (host-checked via slot size)
+constexpr int kTabInts = 2 * kRowsMax + 4;                 // x0[64] | first[64] | total | pad
+constexpr int kVrowCap = 1024 * kMaxIt;                    // widest workgroup (1024 threads) x kMaxIt vectors
+constexpr int kTabBytes = kTabInts * 4 + kVrowCap;         // + row index of every vector (host: march_table_bytes())
+
+// Row spans of a tile's footprint, packed (both marching kernels).  Row `tid` of the box: which columns do the tile's
+// pixels tap there (march_row_span)?  Spans are aligned to ALIGN positions (= one 16-byte vector) and laid back to back:
+//   tab[0..63] = aligned span start x0, tab[64..127] = first vector of the row, tab[128] = vectors per plane,
+//   vrow[v]    = row of vector v (every row's lane writes its own vectors' entries: no search afterwards).
+// The table overlays the ring, which is not in use yet.  Ends with a barrier.
+template <int TH, int TW, int HALO, int ALIGN>
+__device__ __forceinline__ void build_span_table(int* tab, const AffineParams& p, int Ly, double by, double bx, int tid)
+{
+    unsigned char* vrow = reinterpret_cast<unsigned char*>(tab + kTabInts);
+    if (tid < kRowsMax) {
+        const int lane = tid;
+        int mn, mx;
+        const bool used = (tid < Ly) && march_row_span(p.m[5], p.m[6], p.m[9], p.m[10], p.ia1, p.ib1, by, bx, tid, TH, TW, HALO, &mn, &mx);
+        const int x0 = used ? (mn & ~(ALIGN - 1)) : 0;
+        const int nv = used ? ((mx - x0) / ALIGN + 1) : 0;
+        int incl = nv;
+#pragma unroll
+        for (int s2 = 1; s2 < 64; s2 <<= 1) {
+            const int up = __shfl_up(incl, s2);
+            if (lane >= s2) incl += up;
+        }
+        const int first = incl - nv;
+        tab[tid] = x0;
+        tab[kRowsMax + tid] = first;
+        if (tid == kRowsMax - 1) tab[2 * kRowsMax] = incl;
+        const int last = min(first + nv, kVrowCap);            // larger footprints take the fallback path anyway
+        for (int v = first; v < last; ++v) vrow[v] = (unsigned char)tid;
+    }
+    __syncthreads();
+}
 
 template <int KIND, int TH, int TW, int G, int LA, int NT>
 __global__ __launch_bounds__(NT) void affine_march_zsep(const float* __restrict__ src, float* __restrict__ out,
@@ -87,8 +131,9 @@ __global__ __launch_bounds__(NT) void affine_march_zsep(const float* __restrict_
     constexpr int HALO = CUBIC ? 1 : 0;
     constexpr int NR = 2 + 2 * HALO;              // tap rows (and columns) per pixel
     constexpr int NC = 2 * HALO + 1;              // carried partials per pixel
-    static_assert(LA == 1 || LA == 2, "ring depth");
-    constexpr int R = (LA + 1) * G + 2 * HALO + 1;   // ring slots: live group + one group in flight (+ halo planes)
+    // ring slots: live group + `la` groups in flight (+ halo planes); la >= LA is chosen on the host (p.Lz slots)
+    const int R = p.Lz;
+    const int la = (R - 2 * HALO - 1) / G - 1;
     constexpr int RP = NT / TW;
     constexpr int NPIX = TH / RP;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -197,39 +242,13 @@ __global__ __launch_bounds__(NT) void affine_march_zsep(const float* __restrict_
         // tab[0..63]: per-row xmin -> x0 (aligned span start); tab[64..127]: per-row xmax -> first vector of the row;
         // tab[128]: total vectors.  The table overlays the ring (not in use yet).
         int* tab = reinterpret_cast<int*>(lds);
-        if (tid < kRowsMax) {
-            // Row `tid` of the box: which columns do the tile's pixels tap there?  A pixel (j, k) taps the row iff
-            // sy(j,k) lies in [Y-1-HALO, Y+HALO+1); over the continuous pixel rectangle that is a convex polygon, and
-            // the extreme sx over it is attained at a vertex: a rectangle corner inside the strip, or a point where a
-            // strip line crosses a rectangle edge.  (A superset of the taps of the discrete pixels; widened by 1e-6.)
-            int mn, mx;
-            const bool used = (tid < Ly) && march_row_span(p.m[5], p.m[6], p.m[9], p.m[10], by, bx, tid, TH, TW, HALO, &mn, &mx);
-            const int x0 = used ? (mn & ~3) : 0;
-            const int nv = used ? (((mx - x0) >> 2) + 1) : 0;
-            int incl = nv;
-#pragma unroll
-            for (int s2 = 1; s2 < 64; s2 <<= 1) {
-                const int up = __shfl_up(incl, s2);
-                if (lane >= s2) incl += up;
-            }
-            tab[tid] = x0;
-            tab[kRowsMax + tid] = incl - nv;
-            if (tid == kRowsMax - 1) tab[2 * kRowsMax] = incl;
-        }
-        __syncthreads();
+        build_span_table<TH, TW, HALO, 4>(tab, p, Ly, by, bx, tid);
+        const unsigned char* vrow = reinterpret_cast<const unsigned char*>(tab + kTabInts);
         nvec = tab[2 * kRowsMax];
 #pragma unroll
         for (int it = 0; it < kMaxIt; ++it) {
             const int v = tid + NT * it;
-            int y = 0;
-            if (v < nvec) {
-                int a = 0, b = Ly - 1;                // largest row whose first vector is <= v
-                while (a < b) {
-                    const int mid = (a + b + 1) >> 1;
-                    if (tab[kRowsMax + mid] <= v) a = mid; else b = mid - 1;
-                }
-                y = a;
-            }
+            const int y = (v < nvec) ? vrow[v] : 0;
             const int cx = v - tab[kRowsMax + y];
             const int gy = o1 + y, gx = o2 + tab[y] + 4 * cx;
             const bool ok = (v < nvec) && (unsigned)gy < (unsigned)p.sH && (unsigned)gx < (unsigned)p.sP;
@@ -320,34 +339,30 @@ __global__ __launch_bounds__(NT) void affine_march_zsep(const float* __restrict_
             ++P_next;
             slot_next = (slot_next + 1 == R) ? 0 : slot_next + 1;
         }
-        if constexpr (LA == 2) {
-            if (ngroups > 1) {
+        for (int a = 1; a < la && a < ngroups; ++a) {         // groups 1 .. la-1
 #pragma unroll
-                for (int c = 0; c < G; ++c) {                 // group 1
-                    issue_plane(P_next, slot_next);
-                    ++P_next;
-                    slot_next = (slot_next + 1 == R) ? 0 : slot_next + 1;
-                }
+            for (int c = 0; c < G; ++c) {
+                issue_plane(P_next, slot_next);
+                ++P_next;
+                slot_next = (slot_next + 1 == R) ? 0 : slot_next + 1;
             }
         }
         // staging instructions this wave issues per plane: NIT, or NIT-1 when none of its lanes is in the last one
         const bool wave_has_last = __builtin_amdgcn_readfirstlane(tid & ~63) + NT * (NIT - 1) < nvec;
+        const int nload = G * (wave_has_last ? NIT : NIT - 1);    // vector-memory instructions per staged group
+        constexpr int nstore = G * NPIX;                          // ... and per stored group (FAST: never predicated)
         float carry[NPIX][NC];
         int slot_cur = 0;                         // slot of source plane zs(d) - HALO
         int64_t dofs = 0;                         // element offset of output plane d relative to d_begin (wave-uniform)
         for (int g = 0; g < ngroups; ++g, dofs += (int64_t)G * ostride) {
-            if constexpr (LA == 1) {
-                if (FAST && g > 0 && !no_stores) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * NPIX) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            } else {
-                // issued after loads(g): stores(g-2), loads(g+1), stores(g-1)   (steady state, g >= 2 and g+1 < ngroups)
-                if (FAST && g >= 2 && g + 1 < ngroups && !no_stores) {
-                    if (wave_has_last) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G * NPIX + G * NIT) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G * NPIX + G * (NIT - 1)) : "memory");
-                } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            // Iteration j issues [loads(j+la), stores(j)], so after loads(g) this wave has issued stores(max(0,g-la) .. g-1)
+            // and loads(g+1 .. min(g+la-1, ngroups-1)): wait until only those are outstanding.
+            if (FAST && !no_stores && !no_loads) {
+                const int n = min(g, la) * nstore + min(la - 1, ngroups - 1 - g) * nload;
+                wait_vmcnt_le(n);
+            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();         // everyone's loads landed; everyone is done with the slots reused next
-            if (g + LA < ngroups) {
+            if (g + la < ngroups) {
 #pragma unroll
                 for (int c = 0; c < G; ++c) {
                     issue_plane(P_next, slot_next);
@@ -439,7 +454,7 @@ __global__ __launch_bounds__(NT) void affine_march_zsep(const float* __restrict_
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 template <int KIND, int TH, int TW, int LA, int NT>
-__global__ __launch_bounds__(NT) void affine_march_zpair(const float* __restrict__ src2, float* __restrict__ out,
+__global__ __launch_bounds__(NT) VT_ZPAIR_OCC void affine_march_zpair(const float* __restrict__ src2, float* __restrict__ out,
                                                            const AffineParams p)
 {
     static_assert(KIND != 0, "cubic only");
@@ -541,36 +556,13 @@ __global__ __launch_bounds__(NT) void affine_march_zpair(const float* __restrict
     } else {
         // packed row spans (see affine_march_zsep); spans are aligned to 2 positions = one 16-byte vector
         int* tab = reinterpret_cast<int*>(lds);
-        const int lane = tid & 63;
-        if (tid < kRowsMax) {
-            int mn, mx;
-            const bool used = (tid < Ly) && march_row_span(p.m[5], p.m[6], p.m[9], p.m[10], by, bx, tid, TH, TW, HALO, &mn, &mx);
-            const int x0 = used ? (mn & ~1) : 0;
-            const int nv = used ? (((mx - x0) >> 1) + 1) : 0;
-            int incl = nv;
-#pragma unroll
-            for (int s2 = 1; s2 < 64; s2 <<= 1) {
-                const int up = __shfl_up(incl, s2);
-                if (lane >= s2) incl += up;
-            }
-            tab[tid] = x0;
-            tab[kRowsMax + tid] = incl - nv;
-            if (tid == kRowsMax - 1) tab[2 * kRowsMax] = incl;
-        }
-        __syncthreads();
+        build_span_table<TH, TW, HALO, 2>(tab, p, Ly, by, bx, tid);
+        const unsigned char* vrow = reinterpret_cast<const unsigned char*>(tab + kTabInts);
         nvec = tab[2 * kRowsMax];
 #pragma unroll
         for (int it = 0; it < kMaxIt; ++it) {
             const int v = tid + NT * it;
-            int y = 0;
-            if (v < nvec) {
-                int a = 0, b = Ly - 1;
-                while (a < b) {
-                    const int mid = (a + b + 1) >> 1;
-                    if (tab[kRowsMax + mid] <= v) a = mid; else b = mid - 1;
-                }
-                y = a;
-            }
+            const int y = (v < nvec) ? vrow[v] : 0;
             const int cx = v - tab[kRowsMax + y];
             const int gy = o1 + y, gx = o2 + tab[y] + 2 * cx;
             const bool ok = (v < nvec) && (unsigned)gy < (unsigned)p.sH && (unsigned)gx < (unsigned)(p.sP2 >> 1);
@@ -805,6 +797,7 @@ void march_config(int idx, int* th, int* tw, int* g, int* la, int* nt)
 }
 int march_rows_max() { return kRowsMax; }
 int march_max_it() { return kMaxIt; }
+int march_table_bytes() { return kTabBytes; }
 
 template <int TH, int TW, int G, int LA, int NT>
 static march_fn pick_march(int kind)
