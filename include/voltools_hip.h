@@ -130,6 +130,15 @@ int vt_volume_set_output_shape(vt_volume_t* vol, int out_depth, int out_height, 
 int vt_volume_affine(vt_volume_t* vol, const float* m4x4, float* out, int flags);
 int vt_volume_affine_f64(vt_volume_t* vol, const double* m4x4, float* out, int flags);
 
+/* ---- projection: the transformed volume summed over axis 0, without materialising it ----
+ * Replaces `static_volume.transform(...).sum(axis=0)` of examples/projections.py:20-26 (a cupy reduction after the
+ * kernel of volume.py:78).  out_hw: out_height * out_width float32 (host, or device with VT_OUT_DEVICE).
+ * Matrices of the form [1 0 0 tz; 0 a b ty; 0 c d tx] (the example's rotation=(i,0,0) 'sxyz') are computed as one
+ * weighted streaming sum of the resident planes followed by a 2-D interpolation (last_kernel 7); other matrices
+ * transform into an internal buffer and sum it.  Outside voxels contribute 0; VT_KEEP_OUTSIDE is ignored. */
+int vt_volume_project(vt_volume_t* vol, const float* m4x4, float* out_hw, int flags);
+int vt_volume_project_f64(vt_volume_t* vol, const double* m4x4, float* out_hw, int flags);
+
 /* ---- timing: replaces the cupy event pairs of profile=True (transforms.py:167-169,214-219; volume.py:65-67,80-85)
  * Events are recorded on the handle's stream. vt_timer_stop synchronises and returns milliseconds. */
 int vt_timer_start(vt_volume_t* vol);

@@ -246,6 +246,58 @@ def test_reshape_gpu_matches_cpu_interior(golden_volumes, golden_volume):
     assert np.abs(got - ref)[mask].max() <= 2e-6
 
 
+@pytest.mark.parametrize('interp', ALL_INTERPS)
+@pytest.mark.parametrize('shape', [(40, 44, 48), (33, 47, 50)])
+def test_projection_matches_oracle(interp, shape):
+    """sum(axis=0) of the transformed volume: fused path for axis-0-separable matrices (kernel 7),
+    transform + plane sum for the rest; both against the oracle's transformed volume summed in float64."""
+    vol = rand_vol(shape, 7)
+    sv = vt.StaticVolume(vol, interpolation=interp, device='gpu:0')
+    cases = {k: MATRICES[k](shape) for k in ('identity', 'shift_int', 'shift_frac', 'rot_inplane45', 'rot_general', 'shear',
+                                             'far_outside', 'minify')}
+    cases['z_shift_frac'] = vt.utils.translation_matrix((2.5, 0.25, -1.5))
+    cases['z_shift_neg'] = vt.utils.translation_matrix((-3.25, 0, 0))
+    cases['z_shift_out'] = vt.utils.translation_matrix((shape[0] + 5.0, 0, 0))
+    cases['z_shift_edge'] = vt.utils.translation_matrix((shape[0] - 0.75, 0, 0))
+    tol = TOL[interp] * shape[0]
+    for name, m in cases.items():
+        want = oracle.affine(vol, m, interp).astype(np.float64).sum(axis=0)
+        got = sv.projection(m)
+        k = sv.info().last_kernel
+        assert got.shape == shape[1:] and got.dtype == np.float32
+        assert np.abs(got - want).max() <= tol, (interp, name, k, np.abs(got - want).max())
+        separable = name in ('identity', 'shift_int', 'shift_frac', 'rot_inplane45', 'far_outside') or name.startswith('z_')
+        assert (k == 7) == separable, (name, k)
+        # the unfused path gives the same answer
+        got2 = sv.projection(m, _flags=_native.NO_ZSEP)
+        assert sv.info().last_kernel != 7
+        assert np.abs(got2 - want).max() <= tol, (interp, name, 'unfused')
+    # device output, and the keyword form
+    out = vt.empty(shape[1:], device='gpu:0')
+    assert sv.project(rotation=(30, 0, 0), rotation_order='sxyz', output=out) is None
+    m = vt.utils.transform_matrix(rotation=(30, 0, 0), rotation_order='sxyz', center=centre(shape))
+    want = oracle.affine(vol, m, interp).astype(np.float64).sum(axis=0)
+    assert np.abs(out.get() - want).max() <= tol
+    out.free()
+    sv.close()
+
+
+@pytest.mark.parametrize('interp', ['linear', 'bspline'])
+def test_projection_repeated_calls_large_plane(interp):
+    """A plane large enough for the tiled kernels; successive projections must not see stale helper state."""
+    shape = (5, 512, 520)
+    vol = rand_vol(shape, 8)
+    sv = vt.StaticVolume(vol, interpolation=interp, device='gpu:0')
+    for shift, ang in ((0.0, 10.0), (1.5, -35.0), (-0.75, 80.0)):
+        m = vt.utils.transform_matrix(rotation=(ang, 0, 0), rotation_order='sxyz', translation=(shift, 2.0, -3.5),
+                                      center=centre(shape))
+        want = oracle.affine(vol, m, interp).astype(np.float64).sum(axis=0)
+        got = sv.projection(m)
+        assert sv.info().last_kernel == 7
+        assert np.abs(got - want).max() <= TOL[interp] * shape[0], (interp, shift, ang)
+    sv.close()
+
+
 @pytest.mark.parametrize('interp', ['linear', 'filt_bspline'])
 def test_full_size_properties_512(interp):
     """BASELINE sizes: properties that need no CPU oracle pass over 134M voxels."""

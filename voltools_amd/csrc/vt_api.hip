@@ -1,5 +1,6 @@
 // vt_api.hip -- the C ABI of include/voltools_hip.h (hipMalloc / hipMemcpyAsync / kernel launches).
 #include "vt_internal.h"
+#include "vt_device.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -75,6 +76,10 @@ struct vt_volume {
     float* d_src_zp = nullptr;         // second resident copy, planes interleaved in pairs (cubic marching kernel); lazy
     int P2 = 0;                        // floats per pair-row of d_src_zp
     float* d_scratch_out = nullptr;    // staging for host outputs
+    float* d_proj_tmp = nullptr;       // projection of general matrices: the transformed volume before the sum
+    size_t proj_tmp_elems = 0;
+    vt_volume* proj = nullptr;         // projection helper: 3 x H x W volume [S, S, S] sharing this handle's stream
+    bool owns_stream = true;
     size_t scratch_elems = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -640,12 +645,14 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
     return 0;
 }
 
+constexpr int kSrcNone = 1 << 30;   // internal create flag: no source data (zero-filled resident buffer)
+
 int create_common(int dev, int D, int H, int W, int interp, const float* data, int cflags,
                   int64_t plane0, int64_t gD, int64_t out_plane0, int oD, vt_volume_t** out)
 {
     if (!out) return fail(VT_EINVAL, "NULL handle pointer");
     *out = nullptr;
-    if (!data) return fail(VT_EINVAL, "NULL data pointer");
+    if (!data && !(cflags & kSrcNone)) return fail(VT_EINVAL, "NULL data pointer");
     if (D <= 0 || H <= 0 || W <= 0 || oD <= 0) return fail(VT_EINVAL, "non-positive dims (%d,%d,%d) out depth %d", D, H, W, oD);
     if (interp < VT_LINEAR || interp > VT_FILT_BSPLINE_SIMPLE) return fail(VT_EINVAL, "unknown interpolation code %d", interp);
     if ((int64_t)D * H > 0x7fffffffLL || (int64_t)H * W > 0x7fffffffLL) return fail(VT_EUNSUPPORTED, "plane count/size exceeds 2^31");
@@ -692,6 +699,13 @@ int create_common(int dev, int D, int H, int W, int interp, const float* data, i
     VT_HIPC(hipMalloc(reinterpret_cast<void**>(&v->d_zeros), 256));
     VT_HIPC(hipMemsetAsync(v->d_zeros, 0, 256, v->stream));
     const hipMemcpyKind kind = (cflags & VT_SRC_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    if (cflags & kSrcNone) {
+        // internal helper volumes: zero-filled, written by a kernel later
+        VT_HIPC(hipMemsetAsync(v->d_src, 0, bytes, v->stream));
+        VT_HIPC(hipStreamSynchronize(v->stream));
+        *out = v;
+        return 0;
+    }
     // only the pad columns need zeroing (a full memset would cost another 4 B/voxel of HBM writes)
     VT_HIPC(hipMemset2DAsync(v->d_src + W, (size_t)v->P * sizeof(float), 0, (size_t)(v->P - W) * sizeof(float), (size_t)D * H, v->stream));
     {
@@ -726,6 +740,103 @@ int create_common(int dev, int D, int H, int W, int interp, const float* data, i
     }
 #undef VT_HIPC
     *out = v;
+    return 0;
+}
+
+// Axis-0 projection: out[h, w] = sum_d affine(m)[d, h, w]  (see vt_kernels_project.hip)
+int do_project(vt_volume* v, const double m4x4[16], float* out, int flags)
+{
+    if (!v || !m4x4 || !out) return fail(VT_EINVAL, "NULL argument");
+    int rc = use_device(v->dev);
+    if (rc) return rc;
+    for (int i = 0; i < 12; ++i)
+        if (!std::isfinite(m4x4[i])) return fail(VT_EINVAL, "matrix entry %d is not finite", i);
+    // fold the output-plane / slab offsets exactly as do_affine does
+    double m[12];
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 4; ++c) m[4 * r + c] = m4x4[4 * r + c];
+        m[4 * r + 3] = std::fma(m4x4[4 * r], (double)v->out_plane0, m4x4[4 * r + 3]);
+    }
+    m[3] -= (double)v->plane0;
+    const bool host_out = !(flags & VT_OUT_DEVICE);
+    const size_t n2 = (size_t)v->oH * v->oW;
+    const bool zsep = !(flags & VT_NO_ZSEP) && m[0] == 1.0 && m[1] == 0.0 && m[2] == 0.0 && m[4] == 0.0 && m[8] == 0.0 &&
+                      std::fabs(m[3]) < 1.0e9;
+    if (zsep) {
+        if (!v->proj) {
+            const int kind = !is_cubic(v->interp) ? VT_LINEAR
+                             : ((v->interp == VT_BSPLINE_SIMPLE || v->interp == VT_FILT_BSPLINE_SIMPLE) ? VT_BSPLINE_SIMPLE : VT_BSPLINE);
+            vt_volume* h = nullptr;
+            rc = create_common(v->dev, 3, v->H, v->W, kind, nullptr, kSrcNone, 0, 3, 1, 1, &h);
+            if (rc) return rc;
+            hipStreamDestroy(h->stream);         // the helper runs on this handle's stream (ordered after the sum)
+            h->stream = v->stream;
+            h->owns_stream = false;
+            v->proj = h;
+        }
+        vt_volume* h = v->proj;
+        h->oD = 1; h->oH = v->oH; h->oW = v->oW;
+        ProjectParams q;
+        std::memset(&q, 0, sizeof(q));
+        q.D = v->D; q.H = v->H;
+        q.vec = 4; q.nxv = (v->P - 4) / 4;
+        q.src_pitch = v->P; q.dst_pitch = h->P; q.dst_plane = (int64_t)h->H * h->P; q.copies = 3;
+        q.uniform = 0;
+        const double fl = std::floor(m[3]);
+        q.zoff = (int)fl;
+        const float fz = (float)(m[3] - fl);
+        if (!is_cubic(v->interp)) {
+            q.halo = 0; q.ntap = 2; q.wz[0] = 1.0f - fz; q.wz[1] = fz;
+        } else {
+            q.halo = 1; q.ntap = 4;
+            if (v->interp == VT_BSPLINE_SIMPLE || v->interp == VT_FILT_BSPLINE_SIMPLE) cubic_weights<true>(fz, q.wz);
+            else cubic_weights<false>(fz, q.wz);
+        }
+        // valid output planes: 0 <= d < oD and the skirt rule vlo <= d + m[3] < vhi on the resident coordinates
+        const double vlo = -0.5 - (double)v->plane0, vhi = (double)v->gD - 0.5 - (double)v->plane0;
+        const double dlo = std::max(0.0, std::ceil(vlo - m[3])), dhi = std::min((double)v->oD - 1.0, std::ceil(vhi - m[3]) - 1.0);
+        q.dlo = (int)std::max(-1.0e9, std::min(1.0e9, dlo));
+        q.dhi = (int)std::max(-1.0e9, std::min(1.0e9, dhi));
+        VT_HIP(launch_plane_sum(v->d_src, h->d_src, q, v->stream));
+        double m2[16] = {1, 0, 0, 0, 0, m[5], m[6], m[7], 0, m[9], m[10], m[11], 0, 0, 0, 1};
+        // the helper's planes change with every call: no cached pair copy, and a 2-D image does not need LDS staging
+        rc = do_affine(h, m2, out, (flags & VT_OUT_DEVICE) | VT_FORCE_DIRECT);
+        v->last_kernel = 7;
+        v->last_tile[0] = v->last_tile[1] = v->last_tile[2] = 0;
+        v->last_lds[0] = v->last_lds[1] = v->last_lds[2] = 0;
+        v->last_lds_bytes = 0; v->last_grid = 0;
+        return rc;
+    }
+
+    // general matrices: transform into scratch, then sum the planes
+    const size_t n_out = (size_t)v->oD * n2;
+    if (v->proj_tmp_elems < n_out) {
+        if (v->d_proj_tmp) { VT_HIP(hipFree(v->d_proj_tmp)); v->d_proj_tmp = nullptr; v->proj_tmp_elems = 0; }
+        VT_HIP(hipMalloc(reinterpret_cast<void**>(&v->d_proj_tmp), n_out * sizeof(float)));
+        v->proj_tmp_elems = n_out;
+    }
+    rc = do_affine(v, m4x4, v->d_proj_tmp, (flags & ~VT_KEEP_OUTSIDE) | VT_OUT_DEVICE);
+    if (rc) return rc;
+    float* d_out = out;
+    if (host_out) {
+        if (v->scratch_elems < n2) {
+            if (v->d_scratch_out) { VT_HIP(hipFree(v->d_scratch_out)); v->d_scratch_out = nullptr; v->scratch_elems = 0; }
+            VT_HIP(hipMalloc(reinterpret_cast<void**>(&v->d_scratch_out), n2 * sizeof(float)));
+            v->scratch_elems = n2;
+        }
+        d_out = v->d_scratch_out;
+    }
+    ProjectParams q;
+    std::memset(&q, 0, sizeof(q));
+    q.D = v->oD; q.H = v->oH;
+    q.vec = (v->oW % 4 == 0 && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0) ? 4 : 1;
+    q.nxv = v->oW / q.vec;
+    q.src_pitch = v->oW; q.dst_pitch = v->oW; q.dst_plane = 0; q.copies = 1; q.uniform = 1;
+    VT_HIP(launch_plane_sum(v->d_proj_tmp, d_out, q, v->stream));
+    if (host_out) {
+        VT_HIP(hipMemcpyAsync(out, d_out, n2 * sizeof(float), hipMemcpyDeviceToHost, v->stream));
+        VT_HIP(hipStreamSynchronize(v->stream));
+    }
     return 0;
 }
 
@@ -854,9 +965,11 @@ int vt_volume_destroy(vt_volume_t* v)
     if (v->d_zeros) hipFree(v->d_zeros);
     if (v->d_src_zp) hipFree(v->d_src_zp);
     if (v->d_scratch_out) hipFree(v->d_scratch_out);
+    if (v->d_proj_tmp) hipFree(v->d_proj_tmp);
+    if (v->proj) { vt_volume_destroy(v->proj); v->proj = nullptr; }
     if (v->ev0) hipEventDestroy(v->ev0);
     if (v->ev1) hipEventDestroy(v->ev1);
-    if (v->stream) hipStreamDestroy(v->stream);
+    if (v->stream && v->owns_stream) hipStreamDestroy(v->stream);
     delete v;
     return 0;
 }
@@ -912,6 +1025,19 @@ int vt_volume_affine(vt_volume_t* v, const float* m4x4, float* out, int flags)
 int vt_volume_affine_f64(vt_volume_t* v, const double* m4x4, float* out, int flags)
 {
     return do_affine(v, m4x4, out, flags);
+}
+
+int vt_volume_project(vt_volume_t* v, const float* m4x4, float* out_hw, int flags)
+{
+    if (!m4x4) return fail(VT_EINVAL, "NULL matrix");
+    double m[16];
+    for (int i = 0; i < 16; ++i) m[i] = (double)m4x4[i];
+    return do_project(v, m, out_hw, flags);
+}
+
+int vt_volume_project_f64(vt_volume_t* v, const double* m4x4, float* out_hw, int flags)
+{
+    return do_project(v, m4x4, out_hw, flags);
 }
 
 int vt_timer_start(vt_volume_t* v)

@@ -9,7 +9,7 @@ namespace vt {
 // ---------------------------------------------------------------------------------------------------
 
 // bspline.h:102-112
-__device__ __forceinline__ void bspline_weights(float f, float& w0, float& w1, float& w2, float& w3)
+__host__ __device__ __forceinline__ void bspline_weights(float f, float& w0, float& w1, float& w2, float& w3)
 {
     const float one_frac = 1.0f - f;
     const float squared = f * f;
@@ -22,7 +22,7 @@ __device__ __forceinline__ void bspline_weights(float f, float& w0, float& w1, f
 
 // bspline.h:114-122, evaluated at the four tap offsets -1,0,1,2 of cubicTex3DSimple
 // (helper_interpolation.h:51-61): t = |offset - f| lands in the [1,2), [0,1), (0,1], (1,2] branches.
-__device__ __forceinline__ float bspline_fn(float t)
+__host__ __device__ __forceinline__ float bspline_fn(float t)
 {
     t = fabsf(t);
     const float a = 2.0f - t;
@@ -30,7 +30,7 @@ __device__ __forceinline__ float bspline_fn(float t)
 }
 
 template <bool SIMPLE>
-__device__ __forceinline__ void cubic_weights(float f, float (&w)[4])
+__host__ __device__ __forceinline__ void cubic_weights(float f, float (&w)[4])
 {
     if constexpr (SIMPLE) {
         w[0] = bspline_fn(-1.0f - f);

@@ -156,6 +156,22 @@ __host__ __device__ inline bool packed_row_span(const PackGeom& g, int Z, int Y,
     return a <= b;
 }
 
+// Axis-0 projection (vt_kernels_project.hip): dst[y, x] = sum_z c_z * src[z, y, x]
+struct ProjectParams {
+    int32_t D, H;              // planes to sum, rows per plane
+    int32_t nxv;               // column groups per row (VEC floats each)
+    int32_t vec;               // 4: float4 per lane (pitches multiples of 4), 1: scalar
+    int32_t src_pitch;         // floats per source row
+    int32_t dst_pitch;         // floats per destination row
+    int64_t dst_plane;         // floats between the `copies` destination planes
+    int32_t copies;            // the sum is written `copies` times (3 planes of the helper volume)
+    int32_t uniform;           // 1: c_z = 1
+    int32_t zoff, halo, ntap;  // output plane d taps source planes d + zoff - halo + k, k < ntap, with weight wz[k]
+    int32_t dlo, dhi;          // valid output planes (inclusive)
+    float wz[4];
+};
+hipError_t launch_plane_sum(const float* src, float* dst, const ProjectParams& q, hipStream_t stream);
+
 // launchers (vt_kernels_affine.hip)
 int tile_config_count();
 void tile_config(int idx, int* td, int* th, int* tw);

@@ -139,7 +139,6 @@ __global__ __launch_bounds__(NT) void affine_march_zsep(const float* __restrict_
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
     const int t = xcd_contiguous(blockIdx.x, gridDim.x);
     const int tw_i = t % p.nTw;
     const int t2 = t / p.nTw;

@@ -24,10 +24,13 @@ constexpr int kPackRowsMax = 1024;    // (z, y) rows of the bounding box
 // 16 bytes per lane, global memory -> LDS at lds_addr + 16 * lane, without a register round trip.
 // Written as inline assembly: with the builtin, hipcc 7.2 merges the M0 initialisations of an unrolled sequence of
 // direct-to-LDS loads and every load lands on the first destination.  The caller waits with s_waitcnt vmcnt(0).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"      // "m0 is reserved": exactly why it is listed as clobbered
 __device__ __forceinline__ void lds_dma16(const float* g, unsigned lds_addr)
 {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_addr) : "memory", "m0");
 }
+#pragma clang diagnostic pop
 
 template <int KIND, int TD, int TH, int TW>
 __global__ __launch_bounds__(256) void affine_tiled_packed(const float* __restrict__ src, float* __restrict__ out,

@@ -123,6 +123,58 @@ class StaticVolume:
                              translation, center)
         return self.affine(m, profile, output)
 
+
+    # -- projection (examples/projections.py:20-26 does transform(...).sum(axis=0)) -------
+    def projection(self, transform_m: np.ndarray, profile: bool = False, output=None,
+                   _flags: int = 0) -> Union[np.ndarray, None]:
+        """``affine(transform_m).sum(axis=0)`` without materialising the transformed volume.
+
+        Returns a float32 (H, W) numpy array, or fills ``output`` (numpy / device array of that shape) and returns
+        None, like ``affine``.  Rotations about axis 0 (the example's ``rotation=(i, 0, 0)``, ``'sxyz'``) cost one
+        streaming pass over the resident volume plus a 2-D interpolation."""
+        shape2 = tuple(self.shape[1:])
+        if self.device == 'cpu':
+            vol = _affine(self.data, transform_m, interpolation=self.interpolation, profile=profile, device='cpu')
+            proj = vol.sum(axis=0, dtype=np.float64).astype(np.float32)
+            if output is None:
+                return proj
+            output[...] = proj
+            return output
+
+        m = np.asarray(transform_m)
+        flags = _flags
+        if output is None:
+            result = np.empty(shape2, dtype=np.float32)
+            ptr, is_dev = result.ctypes.data, False
+        else:
+            ptr, is_dev, _ = _native.resolve_output(output, shape2, self._dev)
+            result = None
+        if is_dev:
+            flags |= _native.OUT_DEVICE
+        if profile:
+            self.timer_start()
+        if m.dtype == np.float64:
+            m64 = np.ascontiguousarray(m.reshape(4, 4))
+            rc = self._lib.vt_volume_project_f64(self._handle, m64.ctypes.data, ptr, flags)
+        else:
+            m32 = np.ascontiguousarray(m, dtype=np.float32).reshape(4, 4)
+            rc = self._lib.vt_volume_project(self._handle, m32.ctypes.data, ptr, flags)
+        _native.check(rc, 'vt_volume_project')
+        if profile:
+            print(f'projection finished in {self.timer_stop():.3f}ms')
+        return result
+
+    def project(self, scale: Union[float, Vec3] = None, shear: Union[float, Vec3] = None,
+                rotation: Vec3 = None, rotation_units: str = 'deg', rotation_order: str = 'rzxz',
+                translation: Vec3 = None, center: Vec3 = None, profile: bool = False,
+                output=None) -> Union[np.ndarray, None]:
+        """``transform(...)`` followed by ``sum(axis=0)`` (same arguments as ``transform``)."""
+        if center is None:
+            center = np.divide(np.subtract(self.shape, 1), 2, dtype=np.float32)
+        m = transform_matrix(_triple(scale), _triple(shear), rotation, rotation_units, rotation_order,
+                             translation, center)
+        return self.projection(m, profile, output)
+
     def translate(self, translation: Vec3, profile: bool = False, output=None):
         return self.affine(translation_matrix(translation), profile, output)
 
