@@ -89,6 +89,13 @@ def _worker(rank, world, port, counts, interp, reach, matrices, outdir):
                 np.save(os.path.join(outdir, f'out_{i}_{rank}.npy'), out)
             except ValueError as e:
                 open(os.path.join(outdir, f'err_{i}_{rank}.txt'), 'w').write(str(e))
+            try:
+                proj = sv.projection(m)                     # all-reduce over the group: every rank holds the sum
+                np.save(os.path.join(outdir, f'proj_{i}_{rank}.npy'), proj.numpy())
+                part = sv.projection(m, reduce=False)
+                np.save(os.path.join(outdir, f'part_{i}_{rank}.npy'), part.numpy())
+            except ValueError:
+                pass
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -118,6 +125,13 @@ def test_slab_volume_matches_single_volume(world, counts, interp, tmp_path):
         want = oracle.affine(vol, m, interp)
         assert got.shape == want.shape
         assert np.abs(got - want).max() <= tol, (interp, i)
+        # projection: the all-reduced sum is on every rank and equals the sum of the partials and of the whole volume
+        wantp = want.astype(np.float64).sum(axis=0)
+        parts = sum(np.load(tmp_path / f'part_{i}_{r}.npy').astype(np.float64) for r in range(world))
+        for r in range(world):
+            proj = np.load(tmp_path / f'proj_{i}_{r}.npy')
+            assert proj.shape == (H, W) and np.abs(proj - wantp).max() <= tol * G, (interp, i, r)
+            assert np.abs(proj - parts).max() <= 1e-4
 
 
 def test_general_rotation_needs_reach_and_replication_works(tmp_path):

@@ -383,6 +383,7 @@ def test_slab_handles_reproduce_whole_volume(interp):
     tol = TOL[interp] if not interp.startswith('filt') else 2e-5
     for m in mats:
         want = oracle.affine(vol, m, interp)
+        projs = {}
         for flags in (0, _native.NO_ZPAIR, _native.NO_MARCH, _native.NO_ZSEP, _native.FORCE_DIRECT):
             parts = []
             for r, (g0, g1) in enumerate(slab_bounds(counts)):
@@ -396,14 +397,22 @@ def test_slab_handles_reproduce_whole_volume(interp):
                 m32 = np.ascontiguousarray(m, dtype=np.float32)
                 _native.check(lib.vt_volume_affine(h, m32.ctypes.data, out.ctypes.data, flags | _native.FORCE_TILED * (flags != _native.FORCE_DIRECT)),
                               'vt_volume_affine')
+                # the slab's share of the axis-0 projection (fused for flags 0, transform + sum with NO_ZSEP)
+                if flags in (0, _native.NO_ZSEP):
+                    pr = np.empty((H, W), np.float32)
+                    _native.check(lib.vt_volume_project(h, m32.ctypes.data, pr.ctypes.data, flags), 'vt_volume_project')
+                    projs.setdefault(flags, []).append(pr.astype(np.float64))
                 lib.vt_volume_destroy(h)
                 parts.append(out)
             got = np.concatenate(parts)
             assert np.abs(got - want).max() <= tol, (interp, flags)
+        for flags, prs in projs.items():
+            assert np.abs(sum(prs) - want.astype(np.float64).sum(axis=0)).max() <= tol * G, (interp, flags, 'projection')
 
 
+@pytest.mark.timeout(300, method='thread')     # an RCCL bring-up that hangs on a bad box must not hold the whole run
 def test_slab_volume_single_rank_process_group():
-    """The product multi-GPU class end to end on one rank (RCCL process group of size 1)."""
+    """The product multi-GPU class end to end on one rank (RCCL process group of size 1).  Kept last in this file."""
     torch = pytest.importorskip('torch')
     import torch.distributed as dist
     from voltools_amd.distributed import SlabVolume
@@ -426,6 +435,12 @@ def test_slab_volume_single_rank_process_group():
         m = vt.utils.transform_matrix(rotation=(25, -40, 70), rotation_order='sxyz', center=centre(shape))
         got = sv.affine(m)
         assert np.abs(got - oracle.affine(vol, m, 'filt_bspline')).max() <= 1e-5
+        # projection through the slab handle + the (size-1) all-reduce
+        m = vt.utils.transform_matrix(rotation=(0, 30, 0), translation=(1.25, 0, 0), center=centre(shape))
+        proj = sv.projection(m)
+        assert proj.is_cuda and tuple(proj.shape) == shape[1:]
+        want = oracle.affine(vol, m, 'filt_bspline').astype(np.float64).sum(axis=0)
+        assert np.abs(proj.cpu().numpy() - want).max() <= 1e-5 * shape[0]
         sv.close()
     finally:
         dist.destroy_process_group()

@@ -253,6 +253,39 @@ class SlabVolume:
             print(f'transform finished in {self.timer_stop():.3f}ms')
         return result
 
+    def projection(self, transform_m: np.ndarray, reduce: bool = True, dst: Optional[int] = None):
+        """``sum(axis=0)`` of the transformed *global* volume: each rank projects its own output planes
+        (``vt_volume_project`` on the slab handle), then the (H, W) partials are summed over the group -- the path's
+        one real exchange step: an RCCL all-reduce of H*W*4 bytes (1024^2: 4 MiB), or a reduce to group rank ``dst``.
+        ``reduce=False`` returns this rank's partial sum.  Returns a float32 torch tensor (H, W) on the slab's device
+        (the result on every rank, or on ``dst`` only)."""
+        import torch
+        import torch.distributed as dist
+        m = np.asarray(transform_m)
+        self.check_reach(m)
+        H, W = self.global_shape[1:]
+        if self._engine is not None:
+            vol = self._engine.affine(m, None)
+            part = torch.from_numpy(np.ascontiguousarray(vol.sum(axis=0, dtype=np.float64).astype(np.float32)))
+        else:
+            part = torch.empty((H, W), dtype=torch.float32, device=torch.device('cuda', self._dev))
+            if m.dtype == np.float64:
+                m64 = np.ascontiguousarray(m.reshape(4, 4))
+                rc = self._lib.vt_volume_project_f64(self._handle, m64.ctypes.data, ctypes.c_void_p(part.data_ptr()),
+                                                     _native.OUT_DEVICE)
+            else:
+                m32 = np.ascontiguousarray(m, dtype=np.float32).reshape(4, 4)
+                rc = self._lib.vt_volume_project(self._handle, m32.ctypes.data, ctypes.c_void_p(part.data_ptr()),
+                                                 _native.OUT_DEVICE)
+            _native.check(rc, 'vt_volume_project')
+            self.synchronize()                 # the handle's stream is not the stream RCCL enqueues on
+        if reduce and self.world > 1:
+            if dst is None:
+                dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
+            else:
+                dist.reduce(part, dst=self._global_rank(dst), op=dist.ReduceOp.SUM, group=self.group)
+        return part
+
     def transform(self, scale=None, shear=None, rotation=None, rotation_units: str = 'deg', rotation_order: str = 'rzxz',
                   translation=None, center=None, profile: bool = False, output=None):
         if center is None:
