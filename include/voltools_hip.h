@@ -130,6 +130,12 @@ int vt_volume_set_output_shape(vt_volume_t* vol, int out_depth, int out_height, 
 int vt_volume_affine(vt_volume_t* vol, const float* m4x4, float* out, int flags);
 int vt_volume_affine_f64(vt_volume_t* vol, const double* m4x4, float* out, int flags);
 
+/* ---- a batch of matrices against one resident volume (the loop of README.md:25-27 / benchmark.py:52-54 in one call)
+ * m4x4s: n x 16 float32; out: n consecutive output volumes.  Volumes up to 96^3 are served by ONE kernel launch
+ * (launch latency, README.md:74, is paid once); larger ones are queued back to back on the handle's stream.
+ * With a host `out` the call returns after the copy back; with VT_OUT_DEVICE it returns after the launch. */
+int vt_volume_affine_batch(vt_volume_t* vol, int n, const float* m4x4s, float* out, int flags);
+
 /* ---- projection: the transformed volume summed over axis 0, without materialising it ----
  * Replaces `static_volume.transform(...).sum(axis=0)` of examples/projections.py:20-26 (a cupy reduction after the
  * kernel of volume.py:78).  out_hw: out_height * out_width float32 (host, or device with VT_OUT_DEVICE).

@@ -282,6 +282,31 @@ def test_projection_matches_oracle(interp, shape):
     sv.close()
 
 
+@pytest.mark.parametrize('interp', ['linear', 'bspline_simple', 'filt_bspline'])
+def test_affine_batch_matches_single_calls(interp):
+    """vt_volume_affine_batch: one launch for small volumes, queued launches for larger ones; host and device outputs."""
+    for shape, n in (((20, 24, 28), 7), ((100, 100, 104), 3)):
+        vol = rand_vol(shape, 9)
+        sv = vt.StaticVolume(vol, interpolation=interp, device='gpu:0')
+        rs = np.random.RandomState(3)
+        ms = np.stack([vt.utils.transform_matrix(rotation=tuple(rs.uniform(-180, 180, 3)), rotation_order='sxyz',
+                                                 translation=tuple(rs.uniform(-2, 2, 3)), center=centre(shape)) for _ in range(n)])
+        ms[1] = np.eye(4)
+        want = np.stack([sv.affine(m) for m in ms])
+        got = sv.affine_batch(ms)
+        assert got.shape == (n,) + shape and np.array_equal(got, want)
+        out = vt.empty((n,) + shape, device='gpu:0')
+        assert sv.affine_batch(ms, output=out) is None
+        sv.synchronize()
+        assert np.array_equal(out.get(), want)
+        out.free()
+        if shape[0] < 50:
+            assert np.abs(got[0] - oracle.affine(vol, ms[0], interp)).max() <= TOL[interp]
+            with pytest.raises(ValueError):
+                sv.affine_batch(np.eye(4))
+        sv.close()
+
+
 @pytest.mark.parametrize('interp', ['linear', 'bspline'])
 def test_projection_repeated_calls_large_plane(interp):
     """A plane large enough for the tiled kernels; successive projections must not see stale helper state."""

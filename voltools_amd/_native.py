@@ -27,7 +27,7 @@ SYMBOLS = [
     'vt_malloc', 'vt_free', 'vt_memset_zero', 'vt_memcpy_h2d', 'vt_memcpy_d2h', 'vt_memcpy_d2d',
     'vt_volume_create', 'vt_volume_create_slab', 'vt_volume_destroy', 'vt_volume_info', 'vt_volume_stream',
     'vt_volume_sync', 'vt_volume_set_output_shape', 'vt_volume_affine', 'vt_volume_affine_f64',
-    'vt_volume_project', 'vt_volume_project_f64',
+    'vt_volume_project', 'vt_volume_project_f64', 'vt_volume_affine_batch',
     'vt_timer_start', 'vt_timer_stop', 'vt_prefilter_inplace', 'vt_affine_oneshot',
     'vt_last_error', 'vt_version',
 ]
@@ -101,6 +101,7 @@ def load():
     L.vt_volume_affine.argtypes = [c_void_p, c_void_p, c_void_p, c_int]
     L.vt_volume_affine_f64.argtypes = [c_void_p, c_void_p, c_void_p, c_int]
     L.vt_volume_project.argtypes = [c_void_p, c_void_p, c_void_p, c_int]
+    L.vt_volume_affine_batch.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_int]
     L.vt_volume_project_f64.argtypes = [c_void_p, c_void_p, c_void_p, c_int]
     L.vt_timer_start.argtypes = [c_void_p]
     L.vt_timer_stop.argtypes = [c_void_p, P(ctypes.c_float)]

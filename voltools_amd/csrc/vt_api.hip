@@ -9,6 +9,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <vector>
 
 using namespace vt;
 
@@ -76,6 +77,9 @@ struct vt_volume {
     float* d_src_zp = nullptr;         // second resident copy, planes interleaved in pairs (cubic marching kernel); lazy
     int P2 = 0;                        // floats per pair-row of d_src_zp
     float* d_scratch_out = nullptr;    // staging for host outputs
+    double* d_batch_m = nullptr;       // batch launches: n x 12 folded matrices
+    std::vector<double> h_batch_m;     // ... and their host staging (must outlive the asynchronous upload)
+    size_t batch_m_cap = 0;
     float* d_proj_tmp = nullptr;       // projection of general matrices: the transformed volume before the sum
     size_t proj_tmp_elems = 0;
     vt_volume* proj = nullptr;         // projection helper: 3 x H x W volume [S, S, S] sharing this handle's stream
@@ -141,8 +145,8 @@ double gather_conflict_factor(double a, double b, int Lx, int ndw = 2)
 {
     double total = 0;
     int samples = 0;
-    for (int oy = 0; oy < 3; ++oy)
-        for (int ox = 0; ox < 3; ++ox) {
+    for (int oy = 0; oy < 2; ++oy)
+        for (int ox = 0; ox < 2; ++ox) {
             const double y0 = 8.0 + 0.37 * oy + 40.0 * std::fabs(std::min(a, 0.0)), x0 = 8.0 + 0.41 * ox + 40.0 * std::fabs(std::min(b, 0.0));
             for (int dw = 0; dw < ndw; ++dw) {
                 int count[32];
@@ -168,7 +172,7 @@ double gather_conflict_factor(double a, double b, int Lx, int ndw = 2)
 // the matrix, as the marching kernel packs it: per source row the tapped span, aligned to 16 bytes.  The tile's sub-voxel
 // position varies from tile to tile, so a 4 x 4 grid of offsets is sampled and a margin added; a tile that still exceeds
 // the slot falls back to a direct gather inside the kernel, so the estimate affects speed only.
-int estimate_packed_vectors(const double m[12], int th, int tw, int halo, int* rows_out)
+int estimate_packed_vectors(const double m[12], int th, int tw, int halo, int rows_cap, int* rows_out)
 {
     const double a1 = m[5], b1 = m[6], a2 = m[9], b2 = m[10];       // d(sy)/dj, d(sy)/dk, d(sx)/dj, d(sx)/dk
     const double ia1 = march_recip(a1), ib1 = march_recip(b1);
@@ -176,13 +180,13 @@ int estimate_packed_vectors(const double m[12], int th, int tw, int halo, int* r
     for (double e : {a1 * (th - 1), b1 * (tw - 1)}) if (e < 0) neg1 += e;
     for (double e : {a2 * (th - 1), b2 * (tw - 1)}) if (e < 0) neg2 += e;
     int worst = 0, worst_rows = 0;
-    for (int oy = 0; oy < 4; ++oy)
-        for (int ox = 0; ox < 4; ++ox) {
+    for (int oy = 0; oy < 3; ++oy)
+        for (int ox = 0; ox < 3; ++ox) {
             // box-relative base exactly as the kernel forms it: lo = base + neg, o = floor(lo) - halo, b = base - o
-            const double fy0 = 0.25 * oy + 0.013, fx0 = 0.25 * ox + 0.017;
+            const double fy0 = 0.33 * oy + 0.013, fx0 = 0.33 * ox + 0.017;
             const double by = fy0 - neg1 + halo, bx = fx0 - neg2 + halo;   // (+ up to 3 for the 16-byte alignment of o2)
             int total = 0, rows = 0;
-            for (int Y = 0; Y < 256; ++Y) {
+            for (int Y = 0; Y < rows_cap; ++Y) {       // rows_cap: the bounding box's rows (+1)
                 int mn, mx;
                 if (!march_row_span(a1, b1, a2, b2, ia1, ib1, by, bx, Y, th, tw, halo, &mn, &mx)) continue;
                 total += ((mx - mn) >> 2) + 2;                   // +1 vector: unknown 16-byte phase of the span start
@@ -271,7 +275,7 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
                 if (!zp_box) {
                     int rows = 0;
                     // packed spans: vectors of 2 positions; the estimate counts 4-position vectors, so double it (loose)
-                    const int vecs = 2 * estimate_packed_vectors(m, th, tw, 1, &rows);
+                    const int vecs = 2 * estimate_packed_vectors(m, th, tw, 1, L[1] + 1, &rows);
                     if (rows > march_rows_max() || L[1] > march_rows_max()) continue;
                     slot_floats = vecs * 4;
                     if (vecs > vec_max) continue;
@@ -304,6 +308,10 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
                 int target_dch = ((int64_t)v->H * v->W <= 512 * 512) ? 64 : 32;
                 if (const char* e = std::getenv("VT_DCH")) target_dch = std::max(2, std::atoi(e));
                 int64_t nchunks = std::max<int64_t>(1, (v->oD + target_dch - 1) / target_dch);
+                // small volumes: shorter chunks until the launch has ~4 workgroups per CU (a 128^3 volume has only 32
+                // in-plane tiles: 64-plane chunks would leave 3/4 of the chip idle), but not below 8 planes per chunk
+                if (!std::getenv("VT_DCH"))
+                    nchunks = std::max(nchunks, std::min<int64_t>((4 * (int64_t)v->cu_count + inplane - 1) / inplane, (v->oD + 7) / 8));
                 const int64_t pair_bytes = (int64_t)v->H * p->sP2 * 4;
                 nchunks = std::max<int64_t>(nchunks, ((int64_t)(v->oD / 2 + 4) * pair_bytes) / 0x60000000LL + 1);
                 int dch = (int)((v->oD + nchunks - 1) / nchunks);
@@ -339,7 +347,7 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
             }
             if (!ok || L[1] > march_rows_max()) continue;
             int rows = 0;
-            const int vecs = estimate_packed_vectors(m, th, tw, cubic ? 1 : 0, &rows);
+            const int vecs = estimate_packed_vectors(m, th, tw, cubic ? 1 : 0, L[1] + 1, &rows);
             if (vecs > vec_max || rows > march_rows_max()) continue;
             int slot_floats = vecs * 4;
             if (march_box) {
@@ -374,6 +382,7 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
                 p->slot_floats = slot_floats;
                 p->flags = (flags & VT_KEEP_OUTSIDE) | (march_box ? (1 << 20) : 0) |
                            (std::getenv("VT_EXP_NOSTORE") ? (1 << 21) : 0) | (std::getenv("VT_EXP_NOLOAD") ? (1 << 22) : 0);
+                break;                            // first fit wins (planning is on the per-call path: keep it cheap)
             }
         }
         if (plan->kind == 4) {
@@ -399,6 +408,8 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
             // at 512^3 (0.379 vs 0.387 ms), 32 at 1024^3 (2.80 vs 2.88 ms)
             const int target_dch = cubic ? (((int64_t)v->H * v->W <= 512 * 512) ? 64 : 32) : 16;
             int64_t nchunks = std::max<int64_t>(1, (v->oD + target_dch - 1) / target_dch);
+            // small volumes: shorter chunks until the launch has ~4 workgroups per CU, not below 4 planes per chunk
+            nchunks = std::max(nchunks, std::min<int64_t>((4 * (int64_t)v->cu_count + inplane - 1) / inplane, (v->oD + 3) / 4));
             // the chunk's planes are addressed with a 31-bit scalar byte offset from its first plane
             const int64_t plane_bytes = (int64_t)v->H * v->P * 4;
             nchunks = std::max<int64_t>(nchunks, ((int64_t)v->oD * plane_bytes) / 0x60000000LL + 1);
@@ -743,6 +754,79 @@ int create_common(int dev, int D, int H, int W, int interp, const float* data, i
     return 0;
 }
 
+// n transforms of one resident volume in one call.  Small volumes (the launch-latency regime: template
+// rotations, sub-tomogram alignment) take ONE launch of the batched direct kernel, 65535 matrices at a time; larger
+// ones are queued back to back on the handle's stream without returning to the caller in between.
+int do_affine_batch(vt_volume* v, int n, const double* m4x4s, float* out, int flags)
+{
+    if (!v || !m4x4s || !out) return fail(VT_EINVAL, "NULL argument");
+    if (n <= 0) return fail(VT_EINVAL, "batch size %d", n);
+    int rc = use_device(v->dev);
+    if (rc) return rc;
+    const size_t n_out = (size_t)v->oD * v->oH * v->oW;
+    const bool host_out = !(flags & VT_OUT_DEVICE);
+    const bool small = n_out <= (size_t)96 * 96 * 96 && !(flags & VT_FORCE_TILED);
+    if (!small) {
+        for (int i = 0; i < n; ++i) {
+            rc = do_affine(v, m4x4s + 16 * (size_t)i, out + (size_t)i * n_out, flags);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    for (size_t i = 0; i < (size_t)n * 16; ++i)
+        if (!std::isfinite(m4x4s[i])) return fail(VT_EINVAL, "matrix %zu entry %zu is not finite", i / 16, i % 16);
+    // fold the output-plane / slab offsets exactly as do_affine does
+    VT_HIP(hipStreamSynchronize(v->stream));          // the previous batch may still be reading the staging vector
+    std::vector<double>& ms = v->h_batch_m;
+    ms.resize((size_t)n * 12);
+    for (int i = 0; i < n; ++i) {
+        const double* a = m4x4s + 16 * (size_t)i;
+        double* m = ms.data() + 12 * (size_t)i;
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 4; ++c) m[4 * r + c] = a[4 * r + c];
+            m[4 * r + 3] = std::fma(a[4 * r], (double)v->out_plane0, a[4 * r + 3]);
+        }
+        m[3] -= (double)v->plane0;
+    }
+    AffineParams p;
+    std::memset(&p, 0, sizeof(p));
+    TilePlan plan;
+    rc = plan_launch(v, ms.data(), (flags & VT_KEEP_OUTSIDE) | VT_FORCE_DIRECT, &p, &plan);   // dims, valid interval, flags
+    if (rc) return rc;
+    if (v->batch_m_cap < ms.size()) {
+        if (v->d_batch_m) { VT_HIP(hipFree(v->d_batch_m)); v->d_batch_m = nullptr; v->batch_m_cap = 0; }
+        VT_HIP(hipMalloc(reinterpret_cast<void**>(&v->d_batch_m), ms.size() * sizeof(double)));
+        v->batch_m_cap = ms.size();
+    }
+    VT_HIP(hipMemcpyAsync(v->d_batch_m, ms.data(), ms.size() * sizeof(double), hipMemcpyHostToDevice, v->stream));
+    float* d_out = out;
+    const size_t total = n_out * (size_t)n;
+    if (host_out) {
+        if (v->scratch_elems < total) {
+            if (v->d_scratch_out) { VT_HIP(hipFree(v->d_scratch_out)); v->d_scratch_out = nullptr; v->scratch_elems = 0; }
+            VT_HIP(hipMalloc(reinterpret_cast<void**>(&v->d_scratch_out), total * sizeof(float)));
+            v->scratch_elems = total;
+        }
+        d_out = v->d_scratch_out;
+        if (flags & VT_KEEP_OUTSIDE) VT_HIP(hipMemcpyAsync(d_out, out, total * sizeof(float), hipMemcpyHostToDevice, v->stream));
+    }
+    for (int first = 0; first < n; first += 65535) {
+        const int cnt = std::min(65535, n - first);
+        VT_HIP(launch_affine_direct_batch(v->interp, v->d_src, d_out + (size_t)first * n_out, v->d_batch_m + 12 * (size_t)first,
+                                          cnt, p, v->stream));
+    }
+    v->last_kernel = 1;
+    v->last_tile[0] = v->last_tile[1] = v->last_tile[2] = 0;
+    v->last_lds[0] = v->last_lds[1] = v->last_lds[2] = 0;
+    v->last_lds_bytes = 0; v->last_grid = (int)((n_out + 255) / 256);
+    if (host_out) {
+        PinnedScope pin(out, total * sizeof(float));
+        VT_HIP(hipMemcpyAsync(out, d_out, total * sizeof(float), hipMemcpyDeviceToHost, v->stream));
+        VT_HIP(hipStreamSynchronize(v->stream));
+    }
+    return 0;
+}
+
 // Axis-0 projection: out[h, w] = sum_d affine(m)[d, h, w]  (see vt_kernels_project.hip)
 int do_project(vt_volume* v, const double m4x4[16], float* out, int flags)
 {
@@ -966,6 +1050,7 @@ int vt_volume_destroy(vt_volume_t* v)
     if (v->d_src_zp) hipFree(v->d_src_zp);
     if (v->d_scratch_out) hipFree(v->d_scratch_out);
     if (v->d_proj_tmp) hipFree(v->d_proj_tmp);
+    if (v->d_batch_m) hipFree(v->d_batch_m);
     if (v->proj) { vt_volume_destroy(v->proj); v->proj = nullptr; }
     if (v->ev0) hipEventDestroy(v->ev0);
     if (v->ev1) hipEventDestroy(v->ev1);
@@ -1025,6 +1110,14 @@ int vt_volume_affine(vt_volume_t* v, const float* m4x4, float* out, int flags)
 int vt_volume_affine_f64(vt_volume_t* v, const double* m4x4, float* out, int flags)
 {
     return do_affine(v, m4x4, out, flags);
+}
+
+int vt_volume_affine_batch(vt_volume_t* v, int n, const float* m4x4s, float* out, int flags)
+{
+    if (!m4x4s || n <= 0) return fail(VT_EINVAL, "NULL matrices or empty batch");
+    std::vector<double> m((size_t)n * 16);
+    for (size_t i = 0; i < m.size(); ++i) m[i] = (double)m4x4s[i];
+    return do_affine_batch(v, n, m.data(), out, flags);
 }
 
 int vt_volume_project(vt_volume_t* v, const float* m4x4, float* out_hw, int flags)

@@ -177,6 +177,8 @@ int tile_config_count();
 void tile_config(int idx, int* td, int* th, int* tw);
 hipError_t launch_affine_tiled(int cfg, int interp, bool zsep, const float* src, float* out, const float* zeros16,
                                const AffineParams& p, int grid, int lds_bytes, hipStream_t stream);
+hipError_t launch_affine_direct_batch(int interp, const float* src, float* out, const double* d_ms, int n,
+                                      const AffineParams& p, hipStream_t stream);
 int march_table_bytes();   // LDS bytes the packed-span set-up table needs (overlays the ring)
 int march_config_count();
 void march_config(int idx, int* th, int* tw, int* g, int* la, int* nt);

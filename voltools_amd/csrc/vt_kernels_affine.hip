@@ -412,6 +412,36 @@ __global__ __launch_bounds__(256) void affine_direct(const float* __restrict__ s
     out[idx] = val;
 }
 
+// Batch form for small volumes (launch-latency regime: one launch serves `n` matrices; blockIdx.y = matrix).
+// ms: n x 12 doubles (3x4 pull matrices with the plane offsets folded in); out: n consecutive volumes.
+template <int KIND>
+__global__ __launch_bounds__(256) void affine_direct_batch(const float* __restrict__ src, float* __restrict__ out,
+                                                            const double* __restrict__ ms, const AffineParams p)
+{
+    const int64_t n = (int64_t)p.oD * p.oH * p.oW;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const double* m = ms + 12 * (int64_t)blockIdx.y;              // wave-uniform: scalar loads
+    float* o = out + (int64_t)blockIdx.y * n;
+    const int w = (int)(idx % p.oW);
+    const int64_t r2 = idx / p.oW;
+    const int h = (int)(r2 % p.oH);
+    const int d = (int)(r2 / p.oH);
+    double s[3];
+    bool inside = true;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        s[r] = fma(m[4 * r], (double)d, fma(m[4 * r + 1], (double)h, fma(m[4 * r + 2], (double)w, m[4 * r + 3])));
+        inside = inside && (s[r] >= p.vlo[r]) && (s[r] < p.vhi[r]);
+    }
+    if (!inside) {
+        if (!(p.flags & VT_KEEP_OUTSIDE)) o[idx] = 0.0f;
+        return;
+    }
+    const double fzd = floor(s[0]), fyd = floor(s[1]), fxd = floor(s[2]);
+    o[idx] = direct_sample<KIND>(src, p, (int)fzd, (int)fyd, (int)fxd, (float)(s[0] - fzd), (float)(s[1] - fyd), (float)(s[2] - fxd));
+}
+
 // ---------------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------------
@@ -497,6 +527,21 @@ hipError_t launch_affine_direct(int interp, const float* src, float* out, const 
         case 0: hipLaunchKernelGGL(affine_direct<0>, dim3((unsigned)blocks), dim3(256), 0, stream, src, out, p); break;
         case 1: hipLaunchKernelGGL(affine_direct<1>, dim3((unsigned)blocks), dim3(256), 0, stream, src, out, p); break;
         default: hipLaunchKernelGGL(affine_direct<2>, dim3((unsigned)blocks), dim3(256), 0, stream, src, out, p); break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_affine_direct_batch(int interp, const float* src, float* out, const double* d_ms, int n,
+                                      const AffineParams& p, hipStream_t stream)
+{
+    const int64_t nvox = (int64_t)p.oD * p.oH * p.oW;
+    const int64_t blocks = (nvox + 255) / 256;
+    if (blocks > 0x7fffffffLL || n <= 0 || n > 65535) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)blocks, (unsigned)n);
+    switch (interp_kind(interp)) {
+        case 0: hipLaunchKernelGGL(affine_direct_batch<0>, grid, dim3(256), 0, stream, src, out, d_ms, p); break;
+        case 1: hipLaunchKernelGGL(affine_direct_batch<1>, grid, dim3(256), 0, stream, src, out, d_ms, p); break;
+        default: hipLaunchKernelGGL(affine_direct_batch<2>, grid, dim3(256), 0, stream, src, out, d_ms, p); break;
     }
     return hipGetLastError();
 }

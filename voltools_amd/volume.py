@@ -124,6 +124,38 @@ class StaticVolume:
         return self.affine(m, profile, output)
 
 
+    def affine_batch(self, matrices: np.ndarray, profile: bool = False, output=None,
+                     _flags: int = 0) -> Union[np.ndarray, None]:
+        """``affine`` for a stack of matrices (n, 4, 4) in one call.  Returns a float32 array
+        (n, D, H, W), or fills ``output`` of that shape (numpy or device array) and returns None.  Small volumes
+        (<= 96^3: template rotations) are served by a single kernel launch."""
+        ms = np.ascontiguousarray(np.asarray(matrices, dtype=np.float32))
+        if ms.ndim != 3 or ms.shape[1:] != (4, 4) or ms.shape[0] == 0:
+            raise ValueError('matrices must have shape (n, 4, 4)')
+        n = ms.shape[0]
+        shape = (n,) + tuple(self.shape)
+        if self.device == 'cpu':
+            res = np.stack([_affine(self.data, m, interpolation=self.interpolation, device='cpu') for m in ms])
+            if output is None:
+                return res
+            output[...] = res
+            return output
+        flags = _flags
+        if output is None:
+            result = np.empty(shape, dtype=np.float32)
+            ptr, is_dev = result.ctypes.data, False
+        else:
+            ptr, is_dev, _ = _native.resolve_output(output, shape, self._dev)
+            result = None
+        if is_dev:
+            flags |= _native.OUT_DEVICE
+        if profile:
+            self.timer_start()
+        _native.check(self._lib.vt_volume_affine_batch(self._handle, n, ms.ctypes.data, ptr, flags), 'vt_volume_affine_batch')
+        if profile:
+            print(f'{n} transforms finished in {self.timer_stop():.3f}ms')
+        return result
+
     # -- projection (SURVEY 8(f)3; examples/projections.py:20-26 does transform(...).sum(axis=0)) -------
     def projection(self, transform_m: np.ndarray, profile: bool = False, output=None,
                    _flags: int = 0) -> Union[np.ndarray, None]:
