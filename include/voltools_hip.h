@@ -99,6 +99,10 @@ int vt_memset_zero(int dev, void* dptr, size_t bytes);
 int vt_memcpy_h2d(int dev, void* dptr, const void* hptr, size_t bytes);
 int vt_memcpy_d2h(int dev, void* hptr, const void* dptr, size_t bytes);
 int vt_memcpy_d2d(int dev, void* dst, const void* src, size_t bytes);
+/* Pin a caller-owned host range for DMA at PCIe rate (the result-buffer pool of the Python layer keeps its buffers
+ * registered; the reference's `.get()`, transforms.py:223, lands in freshly allocated pageable memory). */
+int vt_host_register(int dev, void* ptr, size_t bytes);
+int vt_host_unregister(int dev, void* ptr);
 
 /* ---- StaticVolume: replaces volume.py:17-59 (upload, optional prefilter, texture build; done once) ----
  * `data` holds depth*height*width float32.  For filt_* interpolations the three-pass prefilter

@@ -66,3 +66,45 @@ def test_product_code_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 for needle in ('import oracle', 'from oracle', 'vt_oracle', 'libvt_oracle', 'oracle/'):
                     assert needle not in text, f'{f} references the oracle ({needle})'
+
+
+def test_host_result_pool_reuses_only_released_buffers(monkeypatch):
+    """_HostResultPool (results of calls without output=): a buffer is recycled only after the caller dropped every
+    view of it; buffers the caller keeps are never handed out again; the cap evicts idle buffers."""
+    import numpy as np
+    from voltools_amd import _native
+
+    class FakeLib:
+        registered = set()
+
+        def vt_host_register(self, dev, ptr, nbytes):
+            self.registered.add(ptr.value)
+            return 0
+
+        def vt_host_unregister(self, dev, ptr):
+            self.registered.discard(ptr.value)
+            return 0
+
+    fake = FakeLib()
+    monkeypatch.setattr(_native, 'load', lambda: fake)
+    pool = _native._HostResultPool()
+    shape = (64, 64, 64)
+    a = pool.take(shape, 0)
+    b = pool.take(shape, 0)
+    pa, pb = a.ctypes.data, b.ctypes.data
+    assert pa != pb and a.shape == shape and a.dtype == np.float32 and {pa, pb} <= fake.registered
+    del a
+    c = pool.take(shape, 0)
+    assert c.ctypes.data == pa                       # released -> recycled
+    view = c[3:5]
+    del c
+    d = pool.take(shape, 0)
+    assert d.ctypes.data not in (pa, pb)             # a live view keeps its buffer out of circulation
+    small = pool.take((4, 4, 4), 0)
+    assert small.ctypes.data not in fake.registered  # tiny results bypass the pool
+    del view, b, d
+    pool.cap = 3 * 64 ** 3 * 4
+    e = pool.take((65, 64, 64), 0)
+    assert sum(x.nbytes for x in pool.entries) <= pool.cap and e.shape == (65, 64, 64)
+    pool.clear()
+    assert not fake.registered

@@ -25,6 +25,7 @@ SRC_DEVICE, SLAB_LO_INTERIOR, SLAB_HI_INTERIOR = 1, 2, 4
 SYMBOLS = [
     'vt_device_count', 'vt_device_name', 'vt_device_props', 'vt_device_synchronize',
     'vt_malloc', 'vt_free', 'vt_memset_zero', 'vt_memcpy_h2d', 'vt_memcpy_d2h', 'vt_memcpy_d2d',
+    'vt_host_register', 'vt_host_unregister',
     'vt_volume_create', 'vt_volume_create_slab', 'vt_volume_destroy', 'vt_volume_info', 'vt_volume_stream',
     'vt_volume_sync', 'vt_volume_set_output_shape', 'vt_volume_affine', 'vt_volume_affine_f64',
     'vt_volume_project', 'vt_volume_project_f64', 'vt_volume_affine_batch',
@@ -89,6 +90,8 @@ def load():
     L.vt_memset_zero.argtypes = [c_int, c_void_p, c_size_t]
     L.vt_memcpy_h2d.argtypes = [c_int, c_void_p, c_void_p, c_size_t]
     L.vt_memcpy_d2h.argtypes = [c_int, c_void_p, c_void_p, c_size_t]
+    L.vt_host_register.argtypes = [c_int, c_void_p, c_size_t]
+    L.vt_host_unregister.argtypes = [c_int, c_void_p]
     L.vt_memcpy_d2d.argtypes = [c_int, c_void_p, c_void_p, c_size_t]
     L.vt_volume_create.argtypes = [c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, P(c_void_p)]
     L.vt_volume_create_slab.argtypes = [c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
@@ -195,6 +198,79 @@ class DeviceArray:
             self.free()
         except Exception:
             pass
+
+
+class _HostResultPool:
+    """Result arrays for calls without ``output=``.
+
+    The reference returns ``cupy_array.get()`` (transforms.py:223, volume.py:89): a freshly allocated numpy array.
+    Writing 512 MiB into fresh pages costs ~45 ms of page faults on the GPU box -- 5x the PCIe transfer itself
+    (tools/pcie_probe.py).  Results therefore come from a small pool of host buffers that stay faulted-in and
+    registered with the HIP runtime: a buffer is handed out again once the caller has dropped every array that
+    views it (reference count of the owner back at the pool's own).  Arrays the caller keeps are never reused.
+    ``VT_HOST_POOL=0`` disables the pool; ``VT_HOST_POOL_MB`` caps it (default 4096)."""
+
+    def __init__(self):
+        self.entries = []          # owner arrays (1-D float32), most recently used last
+        self.enabled = os.environ.get('VT_HOST_POOL', '1') != '0'
+        self.cap = int(os.environ.get('VT_HOST_POOL_MB', '4096')) << 20
+        self.min_bytes = 1 << 20   # small results are not worth a pool slot
+        # reference count of an owner that nobody outside the pool refers to, measured by the scan itself
+        self._idle = self._scan([np.empty(1, dtype=np.float32)], 1, calibrate=True)
+
+    def _scan(self, entries, n, calibrate=False) -> int:
+        """Index of a free buffer of n floats (most recently used first), or -1."""
+        import sys
+        for i in range(len(entries) - 1, -1, -1):
+            e = entries[i]
+            if e.size == n:
+                c = sys.getrefcount(e)
+                if calibrate:
+                    return c
+                if c <= self._idle:
+                    return i
+        return -1
+
+    def take(self, shape, device: int) -> np.ndarray:
+        n = int(np.prod(shape))
+        if not self.enabled or n * 4 < self.min_bytes:
+            return np.empty(shape, dtype=np.float32)
+        i = self._scan(self.entries, n)
+        if i >= 0:
+            self.entries.append(self.entries.pop(i))
+            return self.entries[-1].reshape(shape)
+        # make room: drop free buffers of other sizes, oldest first
+        total = sum(x.nbytes for x in self.entries) + n * 4
+        while total > self.cap:
+            j = -1
+            for size in sorted({x.size for x in self.entries}):
+                j = self._scan(self.entries[::-1], size)        # reversed: oldest first
+                if j >= 0:
+                    j = len(self.entries) - 1 - j
+                    break
+            if j < 0:
+                break
+            victim = self.entries.pop(j)
+            load().vt_host_unregister(device, ctypes.c_void_p(victim.ctypes.data))
+            total -= victim.nbytes
+            del victim
+        owner = np.empty(n, dtype=np.float32)
+        if total <= self.cap and load().vt_host_register(device, ctypes.c_void_p(owner.ctypes.data), owner.nbytes) == 0:
+            self.entries.append(owner)
+        return owner.reshape(shape)
+
+    def clear(self, device: int = 0) -> None:
+        for e in self.entries:
+            load().vt_host_unregister(device, ctypes.c_void_p(e.ctypes.data))
+        self.entries = []
+
+
+_host_pool = _HostResultPool()
+
+
+def host_result(shape, device: int = 0) -> np.ndarray:
+    """A float32 host array for a result that is returned to the caller (see _HostResultPool)."""
+    return _host_pool.take(tuple(int(s) for s in shape), device)
 
 
 def resolve_output(output, shape, device: int) -> Tuple[Optional[int], bool, Optional[np.ndarray]]:

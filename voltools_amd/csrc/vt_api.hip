@@ -1025,6 +1025,24 @@ int vt_memcpy_d2d(int dev, void* dst, const void* src, size_t bytes)
     return 0;
 }
 
+int vt_host_register(int dev, void* ptr, size_t bytes)
+{
+    if (!ptr || !bytes) return fail(VT_EINVAL, "NULL pointer or empty range");
+    int rc = use_device(dev);
+    if (rc) return rc;
+    VT_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return 0;
+}
+
+int vt_host_unregister(int dev, void* ptr)
+{
+    if (!ptr) return 0;
+    int rc = use_device(dev);
+    if (rc) return rc;
+    VT_HIP(hipHostUnregister(ptr));
+    return 0;
+}
+
 int vt_volume_create(int dev, int depth, int height, int width, int interp, const float* data,
                      int create_flags, vt_volume_t** out)
 {

@@ -127,7 +127,7 @@ def _affine_gpu(volume, transform_m, interpolation, reshape, profile, output, de
     m32 = np.ascontiguousarray(np.asarray(transform_m, dtype=np.float32).reshape(4, 4))
 
     if output is None:
-        host_out = np.empty(vol32.shape, dtype=np.float32)
+        host_out = _native.host_result(vol32.shape, dev)
         ptr, is_dev, fill = host_out.ctypes.data, False, None
     else:
         ptr, is_dev, fill = _native.resolve_output(output, vol32.shape, dev)

@@ -91,7 +91,7 @@ class StaticVolume:
         m = np.asarray(transform_m)
         flags = _flags | (_native.KEEP_OUTSIDE if keep_outside else 0)
         if output is None:
-            result = np.empty(self.shape, dtype=np.float32)
+            result = _native.host_result(self.shape, self._dev)
             ptr, is_dev, fill = result.ctypes.data, False, None
             flags &= ~_native.KEEP_OUTSIDE        # a fresh buffer is zero outside (volume.py:73)
         else:
@@ -142,7 +142,7 @@ class StaticVolume:
             return output
         flags = _flags
         if output is None:
-            result = np.empty(shape, dtype=np.float32)
+            result = _native.host_result(shape, self._dev)
             ptr, is_dev = result.ctypes.data, False
         else:
             ptr, is_dev, _ = _native.resolve_output(output, shape, self._dev)
