@@ -538,6 +538,7 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
                 const int64_t ntiles = (int64_t)p->nTd * p->nTh * p->nTw;
                 if (ntiles <= 0x7fffffffLL) {
                     // persistent workgroups: as many as stay resident, a multiple of 8 (one share per XCD)
+                    if (const char* e = std::getenv("VT_TILE_ORDER")) if (std::atoi(e) == 0) p->flags |= (1 << 23);
                     int64_t nwg = std::min<int64_t>(ntiles, (int64_t)v->cu_count * std::max(1, plan->blocks_per_cu));
                     nwg = std::max<int64_t>(8, (nwg + 7) / 8 * 8);
                     plan->grid = (int)nwg;

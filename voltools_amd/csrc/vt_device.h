@@ -56,6 +56,27 @@ __device__ __forceinline__ int xcd_contiguous(int b, int n)
 }
 
 
+// 3-D tiles in 4 x 4 x 4 super-blocks (w fastest inside a block and across blocks): consecutive tile ids -- the tiles
+// that are in flight together on one XCD -- form a compact region of the volume, so the footprints that neighbouring
+// tiles share (in all three directions) are fetched from HBM once and then hit the XCD's L2.  With the plain
+// (d, h, w) order a tile's d-neighbour is nTh*nTw tiles away and its share of the footprint always misses.
+// Returns false for ids that fall outside the tile grid (partial super-blocks); ids run to blocked_tile_count().
+__host__ __device__ __forceinline__ int blocked_tile_count(int nTd, int nTh, int nTw)
+{
+    return ((nTd + 3) >> 2) * ((nTh + 3) >> 2) * ((nTw + 3) >> 2) * 64;
+}
+__device__ __forceinline__ bool blocked_tile(int t, int nTd, int nTh, int nTw, int& td, int& th, int& tw)
+{
+    const int nSh = (nTh + 3) >> 2, nSw = (nTw + 3) >> 2;
+    const int sb = t >> 6, l = t & 63;
+    const int sw = sb % nSw, s2 = sb / nSw;
+    const int sh = s2 % nSh, sd = s2 / nSh;
+    td = sd * 4 + (l >> 4);
+    th = sh * 4 + ((l >> 2) & 3);
+    tw = sw * 4 + (l & 3);
+    return td < nTd && th < nTh && tw < nTw;
+}
+
 // Q32.32 fixed-point coordinate: hi = integer part (box index), lo = fraction.  Stepping along the tile's
 // depth axis is two full-rate integer adds per axis instead of float64 arithmetic; the split into
 // (index, fraction) is free.  For ordinary matrices (float32 entries of moderate magnitude) the arithmetic

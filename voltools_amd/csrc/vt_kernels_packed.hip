@@ -125,12 +125,16 @@ __global__ __launch_bounds__(256) void affine_tiled_packed(const float* __restri
     // is a multiple of 8, so vb lands on the same XCD as this workgroup and xcd_contiguous() keeps every XCD on a
     // contiguous range of tiles.
     const int nwg = gridDim.x;
-    for (int vb = blockIdx.x; vb < ntiles; vb += nwg) {
-        const int t = xcd_contiguous(vb, ntiles);
-        const int tw_i = t % p.nTw;
-        const int t2 = t / p.nTw;
-        const int th_i = t2 % p.nTh;
-        const int td_i = t2 / p.nTh;
+    const int nvirt = (p.flags & (1 << 23)) ? ntiles : blocked_tile_count(p.nTd, p.nTh, p.nTw);
+    for (int vb = blockIdx.x; vb < nvirt; vb += nwg) {
+        const int t = xcd_contiguous(vb, nvirt);
+        int td_i, th_i, tw_i;
+        if (p.flags & (1 << 23)) {                        // plain (d, h, w) order (VT_TILE_ORDER=0, experiments)
+            tw_i = t % p.nTw;
+            const int t2 = t / p.nTw;
+            th_i = t2 % p.nTh;
+            td_i = t2 / p.nTh;
+        } else if (!blocked_tile(t, p.nTd, p.nTh, p.nTw, td_i, th_i, tw_i)) continue;
         const int d0 = td_i * TD, h0 = th_i * TH, w0 = tw_i * TW;
         const int nd = min(TD, p.oD - d0);
 
