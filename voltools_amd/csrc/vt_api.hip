@@ -75,6 +75,8 @@ struct vt_volume {
     float* d_src = nullptr;
     float* d_zeros = nullptr;          // 16 bytes of zeros: the border fetch target of the tiled kernel
     float* d_src_zp = nullptr;         // second resident copy, planes interleaved in pairs (cubic marching kernel); lazy
+    float* d_src_t = nullptr;          // resident copy with axes 0 and 1 exchanged (rotations about axis 1 march along it); lazy
+    float* d_src_t_zp = nullptr;       // ... and its plane-pair form; lazy
     int P2 = 0;                        // floats per pair-row of d_src_zp
     float* d_scratch_out = nullptr;    // staging for host outputs
     double* d_batch_m = nullptr;       // batch launches: n x 12 folded matrices
@@ -215,6 +217,7 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
         if ((step - fl) * 4294967296.0 + 0.5 >= 4294967296.0) { p->inc_lo[r] = 0; p->inc_hi[r] += 1; }
     }
     p->oD = v->oD; p->oH = v->oH; p->oW = v->oW;
+    p->ostride = (int64_t)v->oH * v->oW; p->orow = v->oW;
     p->ia1 = march_recip(m[5]); p->ib1 = march_recip(m[6]);
     p->flags = (flags & VT_KEEP_OUTSIDE);
     // skirt rule src + 0.5 in [0, dim) on the global volume, expressed on resident coordinates
@@ -592,10 +595,54 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
     AffineParams p;
     std::memset(&p, 0, sizeof(p));
     TilePlan plan;
-    rc = plan_launch(v, m, flags, &p, &plan);
-    if (rc) return rc;
-
+    plan.kind = 0;
+    // Rotations about axis 1 ([a 0 b; 0 1 0; c 0 d]): the same problem with axes 0 and 1 exchanged is axis-0-separable.
+    // A second resident copy with those axes exchanged (built once, lazily) lets the marching kernels serve it; only
+    // the output addressing changes (plane stride oW, row stride oH*oW).  Whole-volume handles only (no slab offsets).
+    const float* src_plain = v->d_src;
+    float** pair_slot = &v->d_src_zp;
+    int srcD = v->D, srcH = v->H;
     const size_t n_out = (size_t)v->oD * v->oH * v->oW;
+    const bool ysep = !(flags & (VT_NO_ZSEP | VT_NO_MARCH | VT_FORCE_DIRECT)) && m[5] == 1.0 && m[4] == 0.0 && m[6] == 0.0 &&
+                      m[1] == 0.0 && m[9] == 0.0 && std::fabs(m[7]) < 1.0e9 &&
+                      !(m[0] == 1.0 && m[2] == 0.0 && m[8] == 0.0) &&
+                      v->plane0 == 0 && v->out_plane0 == 0 && v->gD == v->D &&
+                      (n_out >= (size_t)64 * 64 * 64 || (flags & VT_FORCE_TILED));
+    if (ysep) {
+        vt_volume sw;
+        sw.dev = v->dev; sw.interp = v->interp;
+        sw.D = v->H; sw.H = v->D; sw.W = v->W; sw.P = v->P;
+        sw.oD = v->oH; sw.oH = v->oD; sw.oW = v->oW;
+        sw.plane0 = 0; sw.gD = v->H; sw.out_plane0 = 0;
+        sw.lds_limit = v->lds_limit; sw.cu_count = v->cu_count; sw.force_cfg = v->force_cfg; sw.force_la = v->force_la;
+        const int pi[3] = {1, 0, 2};
+        double ms[12];
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) ms[4 * r + c] = m[4 * pi[r] + pi[c]];
+            ms[4 * r + 3] = m[4 * pi[r] + 3];
+        }
+        AffineParams ps;
+        std::memset(&ps, 0, sizeof(ps));
+        TilePlan plans;
+        rc = plan_launch(&sw, ms, flags, &ps, &plans);
+        if (rc) return rc;
+        if (plans.kind == 4 || plans.kind == 5) {
+            if (!v->d_src_t) {
+                const size_t bytes = (size_t)v->D * v->H * v->P * sizeof(float);
+                VT_HIP(hipMalloc(reinterpret_cast<void**>(&v->d_src_t), bytes));
+                VT_HIP(launch_relayout_swap01(v->d_src, v->d_src_t, v->D, v->H, v->P, v->stream));
+            }
+            p = ps; plan = plans;
+            p.ostride = v->oW; p.orow = (int64_t)v->oH * v->oW;
+            src_plain = v->d_src_t; pair_slot = &v->d_src_t_zp;
+            srcD = v->H; srcH = v->D;
+        }
+    }
+    if (plan.kind == 0) {
+        rc = plan_launch(v, m, flags, &p, &plan);
+        if (rc) return rc;
+    }
+
     float* d_out = out;
     const bool host_out = !(flags & VT_OUT_DEVICE);
     if (host_out) {
@@ -610,15 +657,15 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
     }
 
     if (plan.kind == 5) {
-        if (!v->d_src_zp) {
+        if (!*pair_slot) {
             // build the plane-pair copy of the (prefiltered) resident source once
             v->P2 = p.sP2;
-            const size_t zbytes = (size_t)((v->D + 1) / 2) * v->H * v->P2 * sizeof(float);
-            VT_HIP(hipMalloc(reinterpret_cast<void**>(&v->d_src_zp), zbytes));
-            VT_HIP(hipMemsetAsync(v->d_src_zp, 0, zbytes, v->stream));
-            VT_HIP(launch_relayout_zpair(v->d_src, v->d_src_zp, v->D, v->H, v->W, v->P, v->P2, v->stream));
+            const size_t zbytes = (size_t)((srcD + 1) / 2) * srcH * v->P2 * sizeof(float);
+            VT_HIP(hipMalloc(reinterpret_cast<void**>(pair_slot), zbytes));
+            VT_HIP(hipMemsetAsync(*pair_slot, 0, zbytes, v->stream));
+            VT_HIP(launch_relayout_zpair(src_plain, *pair_slot, srcD, srcH, v->W, v->P, v->P2, v->stream));
         }
-        VT_HIP(launch_affine_zpair(plan.cfg, v->interp, v->d_src_zp, d_out, p, plan.grid, plan.lds_bytes, v->stream));
+        VT_HIP(launch_affine_zpair(plan.cfg, v->interp, *pair_slot, d_out, p, plan.grid, plan.lds_bytes, v->stream));
         v->last_kernel = 5;
         v->last_tile[0] = plan.td; v->last_tile[1] = plan.th; v->last_tile[2] = plan.tw;
         v->last_lds[0] = p.Lz; v->last_lds[1] = p.Ly; v->last_lds[2] = p.Lx;
@@ -630,7 +677,7 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
         v->last_lds[0] = p.Lz; v->last_lds[1] = p.Ly; v->last_lds[2] = p.Lx;
         v->last_lds_bytes = plan.lds_bytes; v->last_grid = plan.grid;
     } else if (plan.kind == 4) {
-        VT_HIP(launch_affine_march(plan.cfg, v->interp, v->d_src, d_out, p, plan.grid, plan.lds_bytes, v->stream));
+        VT_HIP(launch_affine_march(plan.cfg, v->interp, src_plain, d_out, p, plan.grid, plan.lds_bytes, v->stream));
         v->last_kernel = 4;
         v->last_tile[0] = plan.td; v->last_tile[1] = plan.th; v->last_tile[2] = plan.tw;
         v->last_lds[0] = p.Lz; v->last_lds[1] = p.Ly; v->last_lds[2] = p.Lx;
@@ -1067,6 +1114,8 @@ int vt_volume_destroy(vt_volume_t* v)
     if (v->d_src) hipFree(v->d_src);
     if (v->d_zeros) hipFree(v->d_zeros);
     if (v->d_src_zp) hipFree(v->d_src_zp);
+    if (v->d_src_t) hipFree(v->d_src_t);
+    if (v->d_src_t_zp) hipFree(v->d_src_t_zp);
     if (v->d_scratch_out) hipFree(v->d_scratch_out);
     if (v->d_proj_tmp) hipFree(v->d_proj_tmp);
     if (v->d_batch_m) hipFree(v->d_batch_m);

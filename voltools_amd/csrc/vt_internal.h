@@ -37,6 +37,7 @@ struct AffineParams {
     int32_t sP2;               // plane-pair layout: floats per pair-row (2 * (roundup4(W) + 4))
     int32_t zero_off2;         // plane-pair layout: byte offset of a zero vector inside any pair-plane
     double ia1, ib1;           // marching kernels: march_recip(m[1][1]), march_recip(m[1][2])
+    int64_t ostride, orow;     // marching kernels: element stride between output planes / rows (oH*oW, oW unless axes are swapped)
 };
 
 
@@ -187,6 +188,7 @@ void zpair_config(int idx, int* th, int* tw, int* la, int* nt);
 hipError_t launch_affine_zpair(int cfg, int interp, const float* src2, float* out, const AffineParams& p,
                                int grid, int lds_bytes, hipStream_t stream);
 hipError_t launch_relayout_zpair(const float* src, float* dst, int D, int H, int W, int P, int P2, hipStream_t stream);
+hipError_t launch_relayout_swap01(const float* src, float* dst, int D, int H, int P, hipStream_t stream);
 int packed_config_count();
 void packed_config(int idx, int* td, int* th, int* tw);
 int packed_rows_max();

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(NT) void affine_march_zsep(const float* __restrict_
     const bool keep = (p.flags & VT_KEEP_OUTSIDE) != 0;
     // every lane of the workgroup stores exactly one value per pixel and plane -> the number of stores a wave has in
     // flight is known, and the wait before the barrier can leave them (and later loads) outstanding
-    const int64_t ostride = (int64_t)p.oH * p.oW;
+    const int64_t ostride = p.ostride, orow = p.orow;     // element strides of an output plane / row (axis swaps)
     const int kw = tid % TW;
     const int jh0 = tid / TW;
 
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(NT) void affine_march_zsep(const float* __restrict_
             for (int px = 0; px < NPIX; ++px) {
                 const int h = h0 + jh0 + px * RP, w = w0 + kw;
                 if (h < p.oH && w < p.oW) {
-                    float* optr = out + ((int64_t)d_begin * p.oH + h) * p.oW + w;
+                    float* optr = out + (int64_t)d_begin * ostride + (int64_t)h * orow + w;
                     for (int d = d_begin; d < d_end; ++d, optr += ostride) *optr = 0.0f;
                 }
             }
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(NT) void affine_march_zsep(const float* __restrict_
         }
         const double ey = sy + (double)o1, ex = sx + (double)o2;
         in_yx[px] = all_valid || ((ey >= p.vlo[1]) && (ey < p.vhi[1]) && (ex >= p.vlo[2]) && (ex < p.vhi[2]));
-        ooff[px] = ((int64_t)d_begin * p.oH + (h0 + j)) * p.oW + (w0 + kw);
+        ooff[px] = (int64_t)d_begin * ostride + (int64_t)(h0 + j) * orow + (w0 + kw);
     }
 
     int voff[kMaxIt];                             // byte offset inside a source plane of each 16-byte vector this thread stages
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(NT) VT_ZPAIR_OCC void affine_march_zpair(const floa
     all_valid = all_valid && (z_lo >= p.vlo[0]) && (z_hi < p.vhi[0]);
     const bool keep = (p.flags & VT_KEEP_OUTSIDE) != 0;
     const bool exact_stores = (h0 + TH <= p.oH) && (w0 + TW <= p.oW) && (all_valid || !keep);
-    const int64_t ostride = (int64_t)p.oH * p.oW;
+    const int64_t ostride = p.ostride, orow = p.orow;
     const int kw = tid % TW;
     const int jh0 = tid / TW;
 
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(NT) VT_ZPAIR_OCC void affine_march_zpair(const floa
             for (int px = 0; px < NPIX; ++px) {
                 const int h = h0 + jh0 + px * RP, w = w0 + kw;
                 if (h < p.oH && w < p.oW) {
-                    int64_t oo = ((int64_t)d_begin * p.oH + h) * p.oW + w;
+                    int64_t oo = (int64_t)d_begin * ostride + (int64_t)h * orow + w;
                     for (int d = d_begin; d < d_end; ++d, oo += ostride) out[oo] = 0.0f;
                 }
             }
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(NT) VT_ZPAIR_OCC void affine_march_zpair(const floa
         ix[px] = (int)fxd;
         const double ey = sy + (double)o1, ex = sx + (double)o2;
         in_yx[px] = all_valid || ((ey >= p.vlo[1]) && (ey < p.vhi[1]) && (ex >= p.vlo[2]) && (ex < p.vhi[2]));
-        ooff[px] = ((int64_t)(h0 + j)) * p.oW + (w0 + kw);
+        ooff[px] = (int64_t)(h0 + j) * orow + (w0 + kw);
     }
 
     int voff[kMaxIt];
@@ -765,6 +765,24 @@ __global__ __launch_bounds__(256) void relayout_zpair(const float* __restrict__ 
     const float b = (z1 < D) ? src[((int64_t)z1 * H + y) * P + x] : 0.0f;
     float2* o = reinterpret_cast<float2*>(dst + ((int64_t)pp * H + y) * P2) + x;
     *o = make_float2(a, b);
+}
+
+// plain [z][y][P] -> [y][z][P] (axes 0 and 1 exchanged; whole rows incl. the zero pad move as 16-byte vectors)
+__global__ __launch_bounds__(256) void relayout_swap01(const float4* __restrict__ src, float4* __restrict__ dst, int D, int H, int P4)
+{
+    const int xv = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y, z = blockIdx.z;
+    if (xv >= P4) return;
+    dst[((int64_t)y * D + z) * P4 + xv] = src[((int64_t)z * H + y) * P4 + xv];
+}
+
+hipError_t launch_relayout_swap01(const float* src, float* dst, int D, int H, int P, hipStream_t stream)
+{
+    const dim3 grid((P / 4 + 255) / 256, H, D);
+    if (grid.y > 65535 || grid.z > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(relayout_swap01, grid, dim3(256), 0, stream, reinterpret_cast<const float4*>(src),
+                       reinterpret_cast<float4*>(dst), D, H, P / 4);
+    return hipGetLastError();
 }
 
 hipError_t launch_relayout_zpair(const float* src, float* dst, int D, int H, int W, int P, int P2, hipStream_t stream)
