@@ -249,6 +249,7 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
                 if (v->force_cfg >= 0 && c != v->force_cfg) continue;
                 int th, tw, la, nt;
                 zpair_config(c, &th, &tw, &la, &nt);
+                if (v->force_la > 0) la = std::min(3, v->force_la);
                 const int vec_max = nt * march_max_it();
                 const int T[3] = {1, th, tw};
                 int L[3] = {0, 0, 0};

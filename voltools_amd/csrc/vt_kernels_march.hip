@@ -459,7 +459,9 @@ __global__ __launch_bounds__(NT) VT_ZPAIR_OCC void affine_march_zpair(const floa
     static_assert(KIND != 0, "cubic only");
     static_assert(NT % TW == 0 && TH % (NT / TW) == 0 && NT % 64 == 0, "tile/thread mapping");
     constexpr int HALO = 1;
-    constexpr int R = LA + 1;                     // ring slots (plane pairs)
+    // ring slots (plane pairs): the live pair + `la` pairs in flight; la (1..3) is chosen on the host (p.Lz slots)
+    const int R = p.Lz;
+    const int la = min(max(R - 1, 1), 3);
     constexpr int RP = NT / TW;
     constexpr int NPIX = TH / RP;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -643,8 +645,12 @@ __global__ __launch_bounds__(NT) VT_ZPAIR_OCC void affine_march_zpair(const floa
         }
     };
 
+    int nload_w = 0;                              // staging instructions this wave issues per pair (wave-uniform)
+#pragma unroll
+    for (int it = 0; it < kMaxIt; ++it) nload_w += (wave_first + NT * it < nvec) ? 1 : 0;
+    const int npairs = PpN - Pp0 + 1;
     int Pp_next = Pp0, slot_next = 0;
-    for (int a = 0; a < LA && Pp_next <= PpN; ++a) {
+    for (int a = 0; a < la && Pp_next <= PpN; ++a) {
         issue_pair(Pp_next, slot_next);
         ++Pp_next;
         slot_next = (slot_next + 1 == R) ? 0 : slot_next + 1;
@@ -653,13 +659,16 @@ __global__ __launch_bounds__(NT) VT_ZPAIR_OCC void affine_march_zpair(const floa
 #pragma unroll
     for (int px = 0; px < NPIX; ++px) { c0[px] = 0.f; c1[px] = 0.f; c2[px] = 0.f; }
     int slot_cur = 0;
-    int stores_prev = 0;                          // store instructions this wave issued in the previous iteration
+    int st_hist[3] = {0, 0, 0};                   // store instructions this wave issued in the last three iterations
+    int stores_prev = 0;
     for (int Pp = Pp0; Pp <= PpN; ++Pp) {
-        // this pair's loads have landed; only the previous iteration's stores were issued after them (LA == 1)
-        if (LA == 1 && exact_stores) {
-            if (stores_prev == 2 * NPIX) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPIX) : "memory");
-            else if (stores_prev == NPIX) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIX) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // Iteration j issues [loads(j + la), stores(j)]: after this pair's loads the wave has issued the stores of the last
+        // `la` iterations and the loads of the next la-1 pairs; wait until only those are outstanding.
+        if (exact_stores) {
+            const int i = Pp - Pp0;
+            int n = st_hist[0] + (la > 1 ? st_hist[1] : 0) + (la > 2 ? st_hist[2] : 0);
+            n += min(la - 1, npairs - 1 - i) * nload_w;
+            wait_vmcnt_le(n);
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -748,6 +757,7 @@ __global__ __launch_bounds__(NT) VT_ZPAIR_OCC void affine_march_zpair(const floa
                 }
             }
         }
+        st_hist[2] = st_hist[1]; st_hist[1] = st_hist[0]; st_hist[0] = stores_prev;
         slot_cur = (slot_cur + 1 == R) ? 0 : slot_cur + 1;
     }
 }
