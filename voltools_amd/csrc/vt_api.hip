@@ -265,6 +265,7 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
                 // box vs packed spans: on par at 512^3, packed 7 % faster at 1024^3 (fabric-bound) [measured]
                 bool zp_box = (int64_t)v->H * v->W <= 512 * 512;
                 if (const char* e = std::getenv("VT_MARCH_BOX")) zp_box = std::atoi(e) != 0;
+                const int lx_used = L[2];                         // columns that hold data; the rest is stride padding
                 int best_lx = L[2];
                 double best_f = 1e300;
                 for (int pad = 0; pad <= 30; pad += 2) {         // bank-pair index = (y*Lx + x) mod 32 for ds_read_b64
@@ -288,7 +289,7 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
                 if (bytes > v->lds_limit) continue;
                 plan->kind = 5; plan->cfg = c; plan->td = 2; plan->th = th; plan->tw = tw;
                 plan->lds_bytes = (int)bytes;
-                p->Lz = la + 1; p->Ly = L[1]; p->Lx = L[2];
+                p->Lz = la + 1; p->Ly = L[1]; p->Lx = L[2]; p->Lx_used = lx_used;
                 p->slot_floats = slot_floats;
                 p->flags = (flags & VT_KEEP_OUTSIDE) | (zp_box ? (1 << 20) : 0);
             }
@@ -354,10 +355,12 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
             const int vecs = estimate_packed_vectors(m, th, tw, cubic ? 1 : 0, L[1] + 1, &rows);
             if (vecs > vec_max || rows > march_rows_max()) continue;
             int slot_floats = vecs * 4;
+            int lx_used4 = 0;
             if (march_box) {
                 // full bounding box with the row stride (in 16-byte steps) that predicts the fewest bank conflicts for
                 // this matrix' lane step (m[1][2], m[2][2])
                 L[2] = (L[2] + 3 + 3) & ~3;
+                lx_used4 = L[2];
                 int best_lx = L[2];
                 double best_f = 1e300;
                 for (int pad = 0; pad <= 28; pad += 4) {
@@ -382,7 +385,7 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
                 best = cost;
                 plan->kind = 4; plan->cfg = c; plan->td = g; plan->th = th; plan->tw = tw;
                 plan->lds_bytes = (int)bytes;
-                p->Lz = ring; p->Ly = std::min(L[1], march_rows_max()); p->Lx = L[2];
+                p->Lz = ring; p->Ly = std::min(L[1], march_rows_max()); p->Lx = L[2]; p->Lx_used = lx_used4 ? lx_used4 : L[2];
                 p->slot_floats = slot_floats;
                 p->flags = (flags & VT_KEEP_OUTSIDE) | (march_box ? (1 << 20) : 0) |
                            (std::getenv("VT_EXP_NOSTORE") ? (1 << 21) : 0) | (std::getenv("VT_EXP_NOLOAD") ? (1 << 22) : 0);

@@ -37,6 +37,7 @@ struct AffineParams {
     int32_t sP2;               // plane-pair layout: floats per pair-row (2 * (roundup4(W) + 4))
     int32_t zero_off2;         // plane-pair layout: byte offset of a zero vector inside any pair-plane
     double ia1, ib1;           // marching kernels: march_recip(m[1][1]), march_recip(m[1][2])
+    int32_t Lx_used;           // marching kernels, box mode: columns of a staged row that hold data (the rest of Lx is padding)
     int64_t ostride, orow;     // marching kernels: element stride between output planes / rows (oH*oW, oW unless axes are swapped)
 };
 

@@ -75,9 +75,11 @@ __device__ __forceinline__ float plane_partial_rows(const float* __restrict__ pl
     }
 }
 
-// Register budget of the pair kernel: 4 waves per SIMD (128 VGPRs; the natural allocation is 138 -> 3 waves).
+// Register budget of the pair kernel.  Natural allocation: 138 VGPRs -> 3 waves per SIMD.  Forcing 4 waves (128 VGPRs,
+// 10 spilled) was measured on one box: same time at 512^3, +1-2 % at 1024^3, but 25 % more HBM reads at 20 degrees (more
+// workgroups in flight than the XCD's L2 can keep the halos for) -- so the natural allocation stays.  -DVT_ZPAIR_WAVES=4 to retry.
 #ifndef VT_ZPAIR_WAVES
-#define VT_ZPAIR_WAVES 4
+#define VT_ZPAIR_WAVES 0
 #endif
 #if VT_ZPAIR_WAVES > 0
 #define VT_ZPAIR_OCC __attribute__((amdgpu_waves_per_eu(VT_ZPAIR_WAVES, VT_ZPAIR_WAVES)))
@@ -229,7 +231,8 @@ __global__ __launch_bounds__(NT) void affine_march_zsep(const float* __restrict_
             const int y = v / nvx;
             const int cx = v - y * nvx;
             const int gy = o1 + y, gx = o2 + 4 * cx;
-            const bool ok = (v < nvec) && (unsigned)gy < (unsigned)p.sH && (unsigned)gx < (unsigned)p.sP;
+            // stride-padding columns are never tapped: fetch the zero vector for them instead of source data
+            const bool ok = (v < nvec) && 4 * cx < p.Lx_used && (unsigned)gy < (unsigned)p.sH && (unsigned)gx < (unsigned)p.sP;
             voff[it] = ok ? (gy * p.sP + gx) * 4 : p.zero_off;
         }
 #pragma unroll
@@ -547,7 +550,7 @@ __global__ __launch_bounds__(NT) VT_ZPAIR_OCC void affine_march_zpair(const floa
             const int y = v / nvx;
             const int cx = v - y * nvx;
             const int gy = o1 + y, gx = o2 + 2 * cx;
-            const bool ok = (v < nvec) && (unsigned)gy < (unsigned)p.sH && (unsigned)gx < (unsigned)(p.sP2 >> 1);
+            const bool ok = (v < nvec) && 2 * cx < p.Lx_used && (unsigned)gy < (unsigned)p.sH && (unsigned)gx < (unsigned)(p.sP2 >> 1);
             voff[it] = ok ? (gy * p.sP2 + 2 * gx) * 4 : p.zero_off2;
         }
 #pragma unroll
