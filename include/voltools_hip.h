@@ -77,7 +77,7 @@ typedef struct vt_volume_info {
     int32_t interp;
     int32_t depth, height, width;      /* resident source dims (including any slab halo planes)            */
     int32_t out_depth, out_height, out_width;
-    int32_t last_kernel;               /* 0 none, 1 direct, 2 tiled (boxes), 3 tiled axis-0-separable, 4 marching, 5 marching on plane pairs, 6 tiled (packed footprints) */
+    int32_t last_kernel;               /* 0 none, 1 direct, 2 tiled (boxes), 3 tiled axis-0-separable, 4 marching, 5 marching on plane pairs, 6 tiled (packed footprints), 7 fused projection */
     int32_t last_tile[3];              /* output tile (TD, TH, TW) of the last tiled launch (marching: G, TH, TW) */
     int32_t last_lds_dims[3];          /* staged source box (Lz, Ly, Lx) (marching: ring slots, Ly, Lx)    */
     int32_t last_lds_bytes;

@@ -1141,8 +1141,11 @@ int vt_volume_info(const vt_volume_t* v, vt_volume_info_t* info)
     for (int i = 0; i < 3; ++i) { info->last_tile[i] = v->last_tile[i]; info->last_lds_dims[i] = v->last_lds[i]; }
     info->last_lds_bytes = v->last_lds_bytes; info->last_grid = v->last_grid;
     info->prefilter_ms = v->prefilter_ms;
-    info->resident_bytes = (uint64_t)v->D * v->H * v->P * sizeof(float) +
-                           (v->d_src_zp ? (uint64_t)((v->D + 1) / 2) * v->H * v->P2 * sizeof(float) : 0);
+    const uint64_t plain = (uint64_t)v->D * v->H * v->P * sizeof(float);
+    info->resident_bytes = plain + (v->d_src_zp ? (uint64_t)((v->D + 1) / 2) * v->H * v->P2 * sizeof(float) : 0) +
+                           (v->d_src_t ? plain : 0) +
+                           (v->d_src_t_zp ? (uint64_t)((v->H + 1) / 2) * v->D * v->P2 * sizeof(float) : 0) +
+                           (v->proj ? (uint64_t)3 * v->proj->H * v->proj->P * sizeof(float) : 0);
     return 0;
 }
 
