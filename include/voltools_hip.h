@@ -52,7 +52,8 @@ enum vt_flags {
     VT_NO_MARCH = 32,      /* diagnostic: axis-0-separable matrices use the 3-D tiled kernel, not the marching one */
     VT_NO_ZPAIR = 64,      /* diagnostic: cubic marching on the plain layout instead of the plane-pair copy          */
     VT_NO_PACKED = 128,    /* diagnostic: general matrices use bounding-box tiles, not packed footprints             */
-    VT_FORCE_PACKED = 256  /* diagnostic: packed footprints whenever they fit, even where boxes are cheaper          */
+    VT_FORCE_PACKED = 256, /* diagnostic: packed footprints whenever they fit, even where boxes are cheaper          */
+    VT_FORCE_XSWAP = 512   /* diagnostic: rotations about axis 2 take the axis-exchange path for every interpolation  */
 };
 
 /* flags for vt_volume_create* */

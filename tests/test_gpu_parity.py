@@ -43,6 +43,9 @@ MATRICES = {
     'minify_big': lambda s: vt.utils.transform_matrix(scale=(0.05, 0.05, 0.05), center=centre(s)),
     'far_outside': lambda s: vt.utils.translation_matrix((1e4, 0, 0)),
     'mirror': lambda s: vt.utils.transform_matrix(scale=(-1.0, 1.0, -1.0), center=centre(s)),
+    'rot_axis2': lambda s: vt.utils.transform_matrix(rotation=(0, 0, 33), rotation_order='sxyz', center=centre(s)),
+    'rot_axis2_shift': lambda s: vt.utils.transform_matrix(rotation=(0, 0, -120), rotation_order='sxyz',
+                                                           translation=(1.5, -2.25, 0.75), center=centre(s)),
     'rot_axis1': lambda s: vt.utils.transform_matrix(rotation=(0, 33, 0), rotation_order='sxyz', center=centre(s)),
     'rot_axis1_shift': lambda s: vt.utils.transform_matrix(rotation=(0, -120, 0), rotation_order='sxyz',
                                                            translation=(1.5, -2.25, 0.75), center=centre(s)),
@@ -70,15 +73,16 @@ def test_tiled_and_direct_match_oracle(interp, mname, shape):
     m = MATRICES[mname](shape)
     want = oracle.affine(vol, m, interp)
     kernels = set()
-    for flags in (_native.FORCE_TILED, _native.FORCE_TILED | _native.NO_ZPAIR, _native.FORCE_TILED | _native.NO_MARCH,
+    for flags in (_native.FORCE_TILED | _native.FORCE_XSWAP, _native.FORCE_TILED | _native.FORCE_XSWAP | _native.NO_ZPAIR,
+                  _native.FORCE_TILED, _native.FORCE_TILED | _native.NO_MARCH,
                   _native.FORCE_TILED | _native.NO_ZSEP | _native.FORCE_PACKED, _native.FORCE_TILED | _native.NO_ZSEP | _native.NO_PACKED,
                   _native.FORCE_DIRECT):
         got, info = run_case(vol, m, interp, flags)
         kernels.add(info.last_kernel)
         err = np.abs(got - want).max()
         assert err <= TOL[interp], f'{interp}/{mname}/{shape} flags={flags} kernel={info.last_kernel} err={err}'
-    if mname in ('rot_axis1', 'rot_axis1_shift'):
-        # rotations about axis 1 march along the axis-exchanged resident copy
+    if mname in ('rot_axis1', 'rot_axis1_shift', 'rot_axis2', 'rot_axis2_shift'):
+        # rotations about axis 1 / 2 march along an axis-exchanged resident copy
         assert (4 in kernels) if interp == 'linear' else (5 in kernels and 4 in kernels)
     if mname in ('identity', 'shift_int', 'shift_frac', 'rot_inplane45'):
         assert 3 in kernels and 4 in kernels         # both axis-0-separable kernels were exercised
@@ -374,16 +378,17 @@ def test_full_size_properties_512(interp):
     sv.affine(m, output=out, _flags=_native.NO_PACKED)
     assert sv.info().last_kernel == 2
     assert np.abs(out.get() - b).max() <= tol
-    # rotation about axis 1: marching on the axis-exchanged copy vs the general kernel vs the direct kernel
-    m = vt.utils.transform_matrix(rotation=(0, 33, 0), rotation_order='sxyz', translation=(0.25, 1.5, -2.0), center=centre((n, n, n)))
-    sv.affine(m, output=out)
-    a = out.get()
-    assert sv.info().last_kernel == (4 if interp == 'linear' else 5)
-    sv.affine(m, output=out, _flags=_native.NO_ZSEP)
-    assert sv.info().last_kernel in (2, 6)
-    assert np.abs(a - out.get()).max() <= tol
-    sv.affine(m, output=out, _flags=_native.FORCE_DIRECT)
-    assert np.abs(a - out.get()).max() <= tol
+    # rotation about axis 1 / 2: marching on the axis-exchanged copy vs the general kernel vs the direct kernel
+    for rot in ((0, 33, 0), (0, 0, 33)):
+        m = vt.utils.transform_matrix(rotation=rot, rotation_order='sxyz', translation=(0.25, 1.5, -2.0), center=centre((n, n, n)))
+        sv.affine(m, output=out)
+        a = out.get()
+        assert sv.info().last_kernel == (4 if interp == 'linear' else 5) or (rot[2] and interp == 'linear'), rot
+        sv.affine(m, output=out, _flags=_native.NO_ZSEP)
+        assert sv.info().last_kernel in (2, 6)
+        assert np.abs(a - out.get()).max() <= tol, rot
+        sv.affine(m, output=out, _flags=_native.FORCE_DIRECT)
+        assert np.abs(a - out.get()).max() <= tol, rot
     # in-plane rotation: separable kernel vs general kernel vs direct kernel
     m = vt.utils.transform_matrix(rotation=(0, 33, 0), translation=(0.25, 1.5, -2.0), center=centre((n, n, n)))
     sv.affine(m, output=out)

@@ -16,6 +16,7 @@ ap.add_argument('--size', type=int, default=512)
 ap.add_argument('--interp', default='linear')
 ap.add_argument('--angle', type=float, default=45.0)
 ap.add_argument('--axis1', action='store_true', help='rotation by --angle about array axis 1 (sxyz (0, angle, 0))')
+ap.add_argument('--axis2', action='store_true', help='rotation by --angle about array axis 2 (sxyz (0, 0, angle))')
 ap.add_argument('--general', action='store_true', help='general 3-D rotation (25,-40,70) sxyz instead of in-plane')
 ap.add_argument('--case', default='', help='named matrix from tests/test_gpu_parity.py MATRICES (overrides --angle/--general)')
 ap.add_argument('--iters', type=int, default=10)
@@ -33,6 +34,8 @@ else:
     m = vt.utils.transform_matrix(rotation=(0, args.angle, 0), rotation_order='rzxz', center=c)
 if args.axis1:
     m = vt.utils.transform_matrix(rotation=(0, args.angle, 0), rotation_order='sxyz', center=c)
+if args.axis2:
+    m = vt.utils.transform_matrix(rotation=(0, 0, args.angle), rotation_order='sxyz', center=c)
 if args.case:
     import os, sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))

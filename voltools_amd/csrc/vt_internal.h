@@ -189,6 +189,9 @@ void zpair_config(int idx, int* th, int* tw, int* la, int* nt);
 hipError_t launch_affine_zpair(int cfg, int interp, const float* src2, float* out, const AffineParams& p,
                                int grid, int lds_bytes, hipStream_t stream);
 hipError_t launch_relayout_zpair(const float* src, float* dst, int D, int H, int W, int P, int P2, hipStream_t stream);
+// dst[k][j][i] = src[i][j][k]; element strides: src i*ss0 + j*ss1 + k, dst k*ds0 + j*ds1 + i (vt_kernels_layout.hip)
+hipError_t launch_transpose02(const float* src, float* dst, int n0, int n1, int n2, int64_t ss0, int64_t ss1,
+                              int64_t ds0, int64_t ds1, hipStream_t stream);
 hipError_t launch_relayout_swap01(const float* src, float* dst, int D, int H, int P, hipStream_t stream);
 int packed_config_count();
 void packed_config(int idx, int* td, int* th, int* tw);
