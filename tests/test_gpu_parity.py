@@ -143,19 +143,23 @@ def test_golden_reference_cpu_path_interior(interp, golden_volumes, golden_volum
         assert np.abs(got - ref)[mask].max() <= tol, (interp, case)
 
 
-def test_keep_outside_and_zero_fill():
+@pytest.mark.parametrize('interp', ['linear', 'bspline'])
+def test_keep_outside_and_zero_fill(interp):
+    """Outside voxels of a caller-supplied output: zero by default, untouched with keep_outside (the reference kernel's
+    behaviour, transforms.py:276-278) -- on every kernel family, incl. the axis-exchanged marching paths."""
     shape = (40, 44, 48)
     vol = rand_vol(shape, 4)
-    m = MATRICES['rot_general'](shape)
     stale = np.full(shape, 7.0, dtype=np.float32)
-    for flags in (_native.FORCE_TILED, _native.FORCE_DIRECT):
-        kept, _ = run_case(vol, m, 'linear', flags, keep=True, out_init=stale)
-        zeroed, _ = run_case(vol, m, 'linear', flags, keep=False, out_init=stale)
-        want_keep = oracle.affine(vol, m, 'linear', oracle.KEEP_OUTSIDE, output=stale.copy())
-        want_zero = oracle.affine(vol, m, 'linear')
+    for mname in ('rot_general', 'rot_inplane45', 'rot_axis1_shift', 'rot_axis2_shift', 'shift_frac'):
+        m = MATRICES[mname](shape)
+        want_keep = oracle.affine(vol, m, interp, oracle.KEEP_OUTSIDE, output=stale.copy())
+        want_zero = oracle.affine(vol, m, interp)
         assert (want_keep == 7.0).sum() > 100          # the case does have outside voxels
-        assert np.abs(kept - want_keep).max() <= 2e-6
-        assert np.abs(zeroed - want_zero).max() <= 2e-6
+        for flags in (_native.FORCE_TILED, _native.FORCE_TILED | _native.FORCE_XSWAP, _native.FORCE_DIRECT):
+            kept, _ = run_case(vol, m, interp, flags, keep=True, out_init=stale)
+            zeroed, _ = run_case(vol, m, interp, flags, keep=False, out_init=stale)
+            assert np.abs(kept - want_keep).max() <= 2e-6, (mname, flags)
+            assert np.abs(zeroed - want_zero).max() <= 2e-6, (mname, flags)
 
 
 def test_prefilter_matches_oracle_all_axes_lengths():

@@ -276,6 +276,7 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
                 for (int pad = 0; pad <= 30; pad += 2) {         // bank-pair index = (y*Lx + x) mod 32 for ds_read_b64
                     // [measured at 36 and 144 degrees] every 2 positions of padding cost ~3 % (LDS footprint), a
                     // pathological stride costs 30-50 %: the model flags the pathological ones reliably
+                    if (pad > 0 && L[1] * ((L[2] + pad) / 2) > vec_max) break;     // the padded box must still be stageable
                     const double f = gather_conflict_factor(m[6], m[10], L[2] + pad, 1) * (1.0 + 0.015 * pad);
                     if (f < best_f - 1e-9) { best_f = f; best_lx = L[2] + pad; }
                 }
@@ -369,6 +370,7 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
                 int best_lx = L[2];
                 double best_f = 1e300;
                 for (int pad = 0; pad <= 28; pad += 4) {
+                    if (pad > 0 && L[1] * (L[2] + pad) / 4 > vec_max) break;
                     const double f = gather_conflict_factor(m[6], m[10], L[2] + pad) * (1.0 + 0.015 * pad);
                     if (f < best_f - 1e-9) { best_f = f; best_lx = L[2] + pad; }
                 }
@@ -615,7 +617,7 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
     const bool ysep = !(flags & (VT_NO_ZSEP | VT_NO_MARCH | VT_FORCE_DIRECT)) && m[5] == 1.0 && m[4] == 0.0 && m[6] == 0.0 &&
                       m[1] == 0.0 && m[9] == 0.0 && std::fabs(m[7]) < 1.0e9 &&
                       !(m[0] == 1.0 && m[2] == 0.0 && m[8] == 0.0) &&
-                      v->plane0 == 0 && v->out_plane0 == 0 && v->gD == v->D &&
+                      v->plane0 == 0 && v->out_plane0 == 0 && v->gD == v->D && v->D <= 65535 && v->H <= 65535 &&
                       (n_out >= (size_t)64 * 64 * 64 || (flags & VT_FORCE_TILED));
     if (ysep) {
         vt_volume sw;
@@ -635,12 +637,17 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
         TilePlan plans;
         rc = plan_launch(&sw, ms, flags, &ps, &plans);
         if (rc) return rc;
-        if (plans.kind == 4 || plans.kind == 5) {
-            if (!v->d_src_t) {
-                const size_t bytes = (size_t)v->D * v->H * v->P * sizeof(float);
-                VT_HIP(hipMalloc(reinterpret_cast<void**>(&v->d_src_t), bytes));
+        if ((plans.kind == 4 || plans.kind == 5) && !v->d_src_t) {
+            const size_t bytes = (size_t)v->D * v->H * v->P * sizeof(float);
+            if (hipMalloc(reinterpret_cast<void**>(&v->d_src_t), bytes) != hipSuccess) {
+                (void)hipGetLastError();          // no room for a second copy: the general kernels serve this matrix
+                v->d_src_t = nullptr;
+                plans.kind = 0;
+            } else {
                 VT_HIP(launch_relayout_swap01(v->d_src, v->d_src_t, v->D, v->H, v->P, v->stream));
             }
+        }
+        if (plans.kind == 4 || plans.kind == 5) {
             p = ps; plan = plans;
             p.ostride = v->oW; p.orow = (int64_t)v->oH * v->oW;
             src_plain = v->d_src_t; pair_slot = &v->d_src_t_zp;
@@ -677,20 +684,28 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
         TilePlan plans;
         rc = plan_launch(&sw, ms, flags, &ps, &plans);
         if (rc) return rc;
-        if (plans.kind == 4 || plans.kind == 5) {
-            if (!v->d_src_x) {
-                v->Px = sw.P;
-                const size_t bytes = (size_t)v->W * v->H * v->Px * sizeof(float);
-                VT_HIP(hipMalloc(reinterpret_cast<void**>(&v->d_src_x), bytes));
+        if ((plans.kind == 4 || plans.kind == 5) && v->tmp_x_elems < n_out) {
+            if (v->d_tmp_x) { VT_HIP(hipFree(v->d_tmp_x)); v->d_tmp_x = nullptr; v->tmp_x_elems = 0; }
+            if (hipMalloc(reinterpret_cast<void**>(&v->d_tmp_x), n_out * sizeof(float)) != hipSuccess) {
+                (void)hipGetLastError();          // no room: the general kernels serve this matrix
+                v->d_tmp_x = nullptr;
+                plans.kind = 0;
+            } else v->tmp_x_elems = n_out;
+        }
+        if ((plans.kind == 4 || plans.kind == 5) && !v->d_src_x) {
+            v->Px = sw.P;
+            const size_t bytes = (size_t)v->W * v->H * v->Px * sizeof(float);
+            if (hipMalloc(reinterpret_cast<void**>(&v->d_src_x), bytes) != hipSuccess) {
+                (void)hipGetLastError();
+                v->d_src_x = nullptr;
+                plans.kind = 0;
+            } else {
                 VT_HIP(hipMemsetAsync(v->d_src_x, 0, bytes, v->stream));          // pad columns must be zero
                 VT_HIP(launch_transpose02(v->d_src, v->d_src_x, v->D, v->H, v->W, (int64_t)v->H * v->P, v->P,
                                           (int64_t)v->H * v->Px, v->Px, v->stream));
             }
-            if (v->tmp_x_elems < n_out) {
-                if (v->d_tmp_x) { VT_HIP(hipFree(v->d_tmp_x)); v->d_tmp_x = nullptr; v->tmp_x_elems = 0; }
-                VT_HIP(hipMalloc(reinterpret_cast<void**>(&v->d_tmp_x), n_out * sizeof(float)));
-                v->tmp_x_elems = n_out;
-            }
+        }
+        if (plans.kind == 4 || plans.kind == 5) {
             p = ps; plan = plans;
             src_plain = v->d_src_x; pair_slot = &v->d_src_x_zp;
             srcD = v->W; srcH = v->H; pair_W = v->D; pair_P = v->Px;
