@@ -857,6 +857,8 @@ static const ZpairCfg kZpair[] = {
     {8, 32, 1, 256},     // 1
     {16, 64, 1, 512},    // 2 (measured: slower than 0)
     {32, 64, 1, 1024},   // 3 (measured: on par with 0 at 0/90 degrees, slower at 45)
+    {16, 32, 1, 512},    // 4: one pixel per thread, 8 waves per workgroup
+    {32, 32, 1, 512},    // 5: two pixels per thread, square tile
 };
 template <int TH, int TW, int LA, int NT>
 static zpair_fn pick_zpair(int kind) { return kind == 1 ? affine_march_zpair<1, TH, TW, LA, NT> : affine_march_zpair<2, TH, TW, LA, NT>; }
@@ -866,7 +868,9 @@ static zpair_fn zpair_entry(int cfg, int kind)
         case 0: return pick_zpair<16, 32, 1, 256>(kind);
         case 1: return pick_zpair<8, 32, 1, 256>(kind);
         case 2: return pick_zpair<16, 64, 1, 512>(kind);
-        default: return pick_zpair<32, 64, 1, 1024>(kind);
+        case 3: return pick_zpair<32, 64, 1, 1024>(kind);
+        case 4: return pick_zpair<16, 32, 1, 512>(kind);
+        default: return pick_zpair<32, 32, 1, 512>(kind);
     }
 }
 int zpair_config_count() { return (int)(sizeof(kZpair) / sizeof(kZpair[0])); }
