@@ -84,12 +84,19 @@ def measured_traffic(kernel_prefix):
         except Exception:
             continue
         tot, cnt = 0.0, 0
+        extra = {}
         for name, m in d.get('pmc_mean_per_launch', {}).items():
             if name.startswith(kernel_prefix) and 'hbm_traffic_bytes' in m:
                 tot += m['hbm_traffic_bytes'] * m.get('launches_sampled', 1)
                 cnt += m.get('launches_sampled', 1)
+                # the cubic kernels also report LDS activity and the L2 hit rate (same PMC passes)
+                if 'TCC_HIT_sum' in m and 'TCC_MISS_sum' in m:
+                    extra['l2_hit_rate'] = round(m['TCC_HIT_sum'] / max(1.0, m['TCC_HIT_sum'] + m['TCC_MISS_sum']), 3)
+                if 'SQ_LDS_IDX_ACTIVE' in m:
+                    extra['lds_active_cycles'] = round(m['SQ_LDS_IDX_ACTIVE'])
+                    extra['lds_bank_conflict_cycles'] = round(m.get('SQ_LDS_BANK_CONFLICT', 0.0))
         if cnt:
-            best = {'bytes': tot / cnt, 'source': os.path.basename(f)}
+            best = {'bytes': tot / cnt, 'source': os.path.basename(f), 'extra': extra}
     return best
 
 
@@ -104,11 +111,18 @@ def main():
 
     if not torch.cuda.is_available() or _native.device_count() < 1:
         raise SystemExit('bench.py needs a GPU (the product path has no CPU fallback)')
+    # rehearsal on a one-GPU box: BENCH_ONE_GPU=1 puts every rank on GPU 0 and uses gloo (RCCL wants a GPU per rank)
+    one_gpu = os.environ.get('BENCH_ONE_GPU') == '1'
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if one_gpu:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     dev = f'gpu:{local_rank}'
     n = args.size
     interp = args.interp
@@ -175,6 +189,7 @@ def main():
                      'unit': 'GB/s', 'frac': round(achieved / 8000.0, 4),
                      'traffic': (round(traffic['bytes']) if traffic else None),
                      'traffic_source': (traffic['source'] if traffic else None),
+                     'counters': (traffic['extra'] if traffic else None),
                      'kernel_ms': round(kernel_ms, 4), 'algorithmic_bytes_per_launch': algo_bytes},
     }
 
