@@ -542,7 +542,12 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
                 }
             }
             const bool forced = (flags & VT_FORCE_PACKED) != 0;
-            if (pk.kind == 6 && (plan->kind < 2 || forced || best_bpv < (cubic ? 0.5 : 0.6) * box_bpv)) {
+            // every persistent workgroup pays ~20 us to build its span table and staging descriptors: worth it only when it
+            // then walks several tiles (measured: boxes win up to 250^3, on par at 320^3, packed 1.5x ahead at 512^3)
+            const int64_t pk_tiles = (int64_t)((v->oD + pk.td - 1) / std::max(1, pk.td)) * ((v->oH + pk.th - 1) / std::max(1, pk.th)) *
+                                     ((v->oW + pk.tw - 1) / std::max(1, pk.tw));
+            const bool enough = pk.kind == 6 && pk_tiles >= 6 * (int64_t)v->cu_count * std::max(1, pk.blocks_per_cu);
+            if (pk.kind == 6 && (plan->kind < 2 || forced || (enough && best_bpv < (cubic ? 0.5 : 0.6) * box_bpv))) {
                 *plan = pk;
                 *p = pp;
                 const int T[3] = {plan->td, plan->th, plan->tw};

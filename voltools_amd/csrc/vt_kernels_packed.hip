@@ -94,21 +94,26 @@ __global__ __launch_bounds__(256) void affine_tiled_packed(const float* __restri
     const int jh0 = tid / TW;
     const bool fits = (nvec * 4 <= p.Lx) && (nvec <= 256 * kPackMaxIt);  // p.Lx = footprint buffer capacity in floats
 
+    // row of every vector: each thread writes the entries of its own rows' vectors (no search afterwards); the list
+    // overlays the footprint buffer, which is not in use yet
+    unsigned short* vrow = reinterpret_cast<unsigned short*>(buf);
+    if (fits) {
+        int first = wave_off + incl - local;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = tid * 4 + r;
+            for (int i = 0; i < nv[r]; ++i) vrow[first + i] = (unsigned short)row;
+            first += nv[r];
+        }
+    }
+    __syncthreads();
     // staging descriptors: element offset relative to the box origin, and the packed (z, y, x) of the vector
     int rel[kPackMaxIt], zyx[kPackMaxIt];
     if (fits) {
 #pragma unroll
         for (int it = 0; it < kPackMaxIt; ++it) {
             const int v = tid + 256 * it;
-            int row = 0;
-            if (v < nvec) {
-                int a = 0, b = rows - 1;            // largest row whose first vector is <= v
-                while (a < b) {
-                    const int mid = (a + b + 1) >> 1;
-                    if (rowbase[mid] <= v) a = mid; else b = mid - 1;
-                }
-                row = a;
-            }
+            const int row = (v < nvec) ? vrow[v] : 0;
             const int Z = row / Ly, Y = row - Z * Ly;
             const int xv = rowx0[row] + 4 * (v - rowbase[row]);
             rel[it] = (Z * p.sH + Y) * p.sP + xv;
