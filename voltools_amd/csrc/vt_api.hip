@@ -223,6 +223,7 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
     }
     p->oD = v->oD; p->oH = v->oH; p->oW = v->oW;
     p->ostride = (int64_t)v->oH * v->oW; p->orow = v->oW;
+    p->ord[0] = 0; p->ord[1] = 1; p->ord[2] = 2;
     p->ia1 = march_recip(m[5]); p->ib1 = march_recip(m[6]);
     p->flags = (flags & VT_KEEP_OUTSIDE);
     // skirt rule src + 0.5 in [0, dim) on the global volume, expressed on resident coordinates
@@ -655,6 +656,7 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
         if (plans.kind == 4 || plans.kind == 5) {
             p = ps; plan = plans;
             p.ostride = v->oW; p.orow = (int64_t)v->oH * v->oW;
+            p.ord[0] = 1; p.ord[1] = 0; p.ord[2] = 2;          // original (d, h, w) = this launch's columns (1, 0, 2)
             src_plain = v->d_src_t; pair_slot = &v->d_src_t_zp;
             srcD = v->H; srcH = v->D;
         }
@@ -714,6 +716,7 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
             p = ps; plan = plans;
             src_plain = v->d_src_x; pair_slot = &v->d_src_x_zp;
             srcD = v->W; srcH = v->H; pair_W = v->D; pair_P = v->Px;
+            p.ord[0] = 2; p.ord[1] = 1; p.ord[2] = 0;          // original (d, h, w) = this launch's columns (2, 1, 0)
             xswap = true;
         }
     }

@@ -102,6 +102,35 @@ __device__ __forceinline__ void fx_step(Fx& c, int inc_hi, unsigned inc_lo)
 __device__ __forceinline__ float fx_frac(const Fx& c) { return (float)c.lo * 0x1p-32f; }
 
 // ---------------------------------------------------------------------------------------------------
+// the skirt rule, one definition for every kernel
+// ---------------------------------------------------------------------------------------------------
+// A voxel is inside when vlo <= src < vhi on every axis, with src evaluated by exactly this fma chain -- the one
+// affine_direct and the oracle use.  The tiled kernels form their tap coordinates incrementally (tile base + offsets,
+// fixed-point steps), which differs from this chain by an ulp; a voxel that lands exactly on the skirt (quarter turns about
+// a half-integer centre do that) must not change sides with the kernel, so every per-voxel test goes through here and
+// tiles are only classified as wholly inside / outside when they clear the skirt by kTileMargin.
+constexpr double kTileMargin = 1.0e-6;
+
+__device__ __forceinline__ double canonical_coord(const AffineParams& p, int r, int d, int h, int w)
+{
+    // p.ord: the launch's columns in the order of the ORIGINAL problem's axes (identity unless axes were exchanged)
+    const int c0 = p.ord[0], c1 = p.ord[1], c2 = p.ord[2];
+    const double x0 = (double)(c0 == 0 ? d : (c0 == 1 ? h : w));
+    const double x1 = (double)(c1 == 0 ? d : (c1 == 1 ? h : w));
+    const double x2 = (double)(c2 == 0 ? d : (c2 == 1 ? h : w));
+    return fma(p.m[4 * r + c0], x0, fma(p.m[4 * r + c1], x1, fma(p.m[4 * r + c2], x2, p.m[4 * r + 3])));
+}
+__device__ __forceinline__ bool canonical_inside_axis(const AffineParams& p, int r, int d, int h, int w)
+{
+    const double s = canonical_coord(p, r, d, h, w);
+    return (s >= p.vlo[r]) && (s < p.vhi[r]);
+}
+__device__ __forceinline__ bool canonical_inside(const AffineParams& p, int d, int h, int w)
+{
+    return canonical_inside_axis(p, 0, d, h, w) && canonical_inside_axis(p, 1, d, h, w) && canonical_inside_axis(p, 2, d, h, w);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // direct (untiled) sampling from global memory with explicit border tests
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float fetch0(const float* __restrict__ src, const AffineParams& p, int z, int y, int x)

@@ -38,6 +38,8 @@ struct AffineParams {
     int32_t zero_off2;         // plane-pair layout: byte offset of a zero vector inside any pair-plane
     double ia1, ib1;           // marching kernels: march_recip(m[1][1]), march_recip(m[1][2])
     int32_t Lx_used;           // marching kernels, box mode: columns of a staged row that hold data (the rest of Lx is padding)
+    int32_t ord[3];            // column order of the skirt test's fma chain (0,1,2; permuted when the launch runs on an axis-exchanged copy,
+                               // so that the chain is the original problem's and boundary voxels classify as in affine_direct)
     int64_t ostride, orow;     // marching kernels: element stride between output planes / rows (oH*oW, oW unless axes are swapped)
 };
 

@@ -125,8 +125,8 @@ __global__ __launch_bounds__(256) void affine_tiled(const float* __restrict__ sr
         base[r] = fma(p.m[4 * r], (double)d0, fma(p.m[4 * r + 1], (double)h0, fma(p.m[4 * r + 2], (double)w0, p.m[4 * r + 3])));
         lo[r] = base[r] + p.neg[r];
         hi[r] = base[r] + p.pos[r];
-        any_valid = any_valid && (hi[r] >= p.vlo[r]) && (lo[r] < p.vhi[r]);
-        all_valid = all_valid && (lo[r] >= p.vlo[r]) && (hi[r] < p.vhi[r]);
+        any_valid = any_valid && (hi[r] >= p.vlo[r] - kTileMargin) && (lo[r] < p.vhi[r] + kTileMargin);
+        all_valid = all_valid && (lo[r] >= p.vlo[r] + kTileMargin) && (hi[r] < p.vhi[r] - kTileMargin);
     }
 
     const int kw = tid % TW;
@@ -194,19 +194,14 @@ __global__ __launch_bounds__(256) void affine_tiled(const float* __restrict__ sr
             // tiles cut by the skirt or by the end of the output: the inside test is done on float64
             // coordinates (identical to the direct kernel and the oracle), the taps still come from the
             // fixed-point split
-            double e0 = s0, e1 = s1, e2 = s2;
-            const double vlo0 = p.vlo[0] - (double)o[0], vhi0 = p.vhi[0] - (double)o[0];
-            const double vlo1 = p.vlo[1] - (double)o[1], vhi1 = p.vhi[1] - (double)o[1];
-            const double vlo2 = p.vlo[2] - (double)o[2], vhi2 = p.vhi[2] - (double)o[2];
             for (int i = 0; i < nd; ++i) {
-                const bool inside = (e0 >= vlo0) && (e0 < vhi0) && (e1 >= vlo1) && (e1 < vhi1) && (e2 >= vlo2) && (e2 < vhi2);
+                const bool inside = canonical_inside(p, d0 + i, h, w);
                 const float val = sample_box<KIND>(lds, Lx, LyLx, c0.hi, c1.hi, c2.hi, fx_frac(c0), fx_frac(c1), fx_frac(c2));
                 if (inside) optr[i * ostride] = val;
                 else if (!keep) optr[i * ostride] = 0.0f;
                 fx_step(c0, p.inc_hi[0], p.inc_lo[0]);
                 fx_step(c1, p.inc_hi[1], p.inc_lo[1]);
                 fx_step(c2, p.inc_hi[2], p.inc_lo[2]);
-                e0 += p.m[0]; e1 += p.m[4]; e2 += p.m[8];
             }
         }
     }
@@ -275,13 +270,13 @@ __global__ __launch_bounds__(256) void affine_tiled_zsep(const float* __restrict
         base[r] = fma(p.m[4 * r + 1], (double)h0, fma(p.m[4 * r + 2], (double)w0, p.m[4 * r + 3]));
         lo[r] = base[r] + p.neg[r];
         hi[r] = base[r] + p.pos[r];
-        any_valid = any_valid && (hi[r] >= p.vlo[r]) && (lo[r] < p.vhi[r]);
-        all_valid = all_valid && (lo[r] >= p.vlo[r]) && (hi[r] < p.vhi[r]);
+        any_valid = any_valid && (hi[r] >= p.vlo[r] - kTileMargin) && (lo[r] < p.vhi[r] + kTileMargin);
+        all_valid = all_valid && (lo[r] >= p.vlo[r] + kTileMargin) && (hi[r] < p.vhi[r] - kTileMargin);
     }
     // axis 0: src_z = d + tz exactly; zoff = floor(tz), fz = tz - zoff (host-computed)
     const double z_lo = (double)d0 + p.m[3], z_hi = (double)(d0 + nd - 1) + p.m[3];
-    any_valid = any_valid && (z_hi >= p.vlo[0]) && (z_lo < p.vhi[0]);
-    all_valid = all_valid && (z_lo >= p.vlo[0]) && (z_hi < p.vhi[0]) && (nd == TD);
+    any_valid = any_valid && (z_hi >= p.vlo[0] - kTileMargin) && (z_lo < p.vhi[0] + kTileMargin);
+    all_valid = all_valid && (z_lo >= p.vlo[0] + kTileMargin) && (z_hi < p.vhi[0] - kTileMargin) && (nd == TD);
 
     const int kw = tid % TW;
     const int jh0 = tid / TW;
@@ -331,10 +326,7 @@ __global__ __launch_bounds__(256) void affine_tiled_zsep(const float* __restrict
         float wy[4] = {0.f, 0.f, 0.f, 0.f}, wx[4] = {0.f, 0.f, 0.f, 0.f};
         if constexpr (CUBIC) { cubic_weights<KIND == 2>(fy, wy); cubic_weights<KIND == 2>(fx, wx); }
         bool in_yx = true;
-        if (!all_valid) {
-            const double ey = sy + (double)o[1], ex = sx + (double)o[2];
-            in_yx = (ey >= p.vlo[1]) && (ey < p.vhi[1]) && (ex >= p.vlo[2]) && (ex < p.vhi[2]);
-        }
+        if (!all_valid) in_yx = canonical_inside_axis(p, 1, d0, h, w) && canonical_inside_axis(p, 2, d0, h, w);   // rows 1, 2 ignore d
         const float* q = lds + (__mul24(iy - HALO, Lx) + (ix - HALO));
         float* optr = out + ((int64_t)d0 * p.oH + h) * p.oW + w;
 

@@ -158,12 +158,12 @@ __global__ __launch_bounds__(NT) void affine_march_zsep(const float* __restrict_
         base[r] = fma(p.m[4 * r + 1], (double)h0, fma(p.m[4 * r + 2], (double)w0, p.m[4 * r + 3]));
         lo[r] = base[r] + p.neg[r];
         hi[r] = base[r] + p.pos[r];
-        any_valid = any_valid && (hi[r] >= p.vlo[r]) && (lo[r] < p.vhi[r]);
-        all_valid = all_valid && (lo[r] >= p.vlo[r]) && (hi[r] < p.vhi[r]);
+        any_valid = any_valid && (hi[r] >= p.vlo[r] - kTileMargin) && (lo[r] < p.vhi[r] + kTileMargin);
+        all_valid = all_valid && (lo[r] >= p.vlo[r] + kTileMargin) && (hi[r] < p.vhi[r] - kTileMargin);
     }
     const double z_lo = (double)d_begin + p.m[3], z_hi = (double)(d_end - 1) + p.m[3];
-    any_valid = any_valid && (z_hi >= p.vlo[0]) && (z_lo < p.vhi[0]);
-    all_valid = all_valid && (z_lo >= p.vlo[0]) && (z_hi < p.vhi[0]);
+    any_valid = any_valid && (z_hi >= p.vlo[0] - kTileMargin) && (z_lo < p.vhi[0] + kTileMargin);
+    all_valid = all_valid && (z_lo >= p.vlo[0] + kTileMargin) && (z_hi < p.vhi[0] - kTileMargin);
     const bool keep = (p.flags & VT_KEEP_OUTSIDE) != 0;
     // every lane of the workgroup stores exactly one value per pixel and plane -> the number of stores a wave has in
     // flight is known, and the wait before the barrier can leave them (and later loads) outstanding
@@ -211,8 +211,8 @@ __global__ __launch_bounds__(NT) void affine_march_zsep(const float* __restrict_
 #pragma unroll
             for (int k = 0; k < 4; ++k) { wy[px][k] = 0.f; wx[px][k] = 0.f; }
         }
-        const double ey = sy + (double)o1, ex = sx + (double)o2;
-        in_yx[px] = all_valid || ((ey >= p.vlo[1]) && (ey < p.vhi[1]) && (ex >= p.vlo[2]) && (ex < p.vhi[2]));
+        // rows 1, 2 of an axis-0-separable matrix ignore d
+        in_yx[px] = all_valid || (canonical_inside_axis(p, 1, 0, h0 + j, w0 + kw) && canonical_inside_axis(p, 2, 0, h0 + j, w0 + kw));
         ooff[px] = (int64_t)d_begin * ostride + (int64_t)(h0 + j) * orow + (w0 + kw);
     }
 
@@ -486,12 +486,12 @@ __global__ __launch_bounds__(NT) VT_ZPAIR_OCC void affine_march_zpair(const floa
         base[r] = fma(p.m[4 * r + 1], (double)h0, fma(p.m[4 * r + 2], (double)w0, p.m[4 * r + 3]));
         lo[r] = base[r] + p.neg[r];
         hi[r] = base[r] + p.pos[r];
-        any_valid = any_valid && (hi[r] >= p.vlo[r]) && (lo[r] < p.vhi[r]);
-        all_valid = all_valid && (lo[r] >= p.vlo[r]) && (hi[r] < p.vhi[r]);
+        any_valid = any_valid && (hi[r] >= p.vlo[r] - kTileMargin) && (lo[r] < p.vhi[r] + kTileMargin);
+        all_valid = all_valid && (lo[r] >= p.vlo[r] + kTileMargin) && (hi[r] < p.vhi[r] - kTileMargin);
     }
     const double z_lo = (double)d_begin + p.m[3], z_hi = (double)(d_end - 1) + p.m[3];
-    any_valid = any_valid && (z_hi >= p.vlo[0]) && (z_lo < p.vhi[0]);
-    all_valid = all_valid && (z_lo >= p.vlo[0]) && (z_hi < p.vhi[0]);
+    any_valid = any_valid && (z_hi >= p.vlo[0] - kTileMargin) && (z_lo < p.vhi[0] + kTileMargin);
+    all_valid = all_valid && (z_lo >= p.vlo[0] + kTileMargin) && (z_hi < p.vhi[0] - kTileMargin);
     const bool keep = (p.flags & VT_KEEP_OUTSIDE) != 0;
     const bool exact_stores = (h0 + TH <= p.oH) && (w0 + TW <= p.oW) && (all_valid || !keep);
     const int64_t ostride = p.ostride, orow = p.orow;
@@ -533,8 +533,8 @@ __global__ __launch_bounds__(NT) VT_ZPAIR_OCC void affine_march_zpair(const floa
         cubic_weights<KIND == 2>((float)(sx - fxd), wx[px]);
         iy[px] = (int)fyd;
         ix[px] = (int)fxd;
-        const double ey = sy + (double)o1, ex = sx + (double)o2;
-        in_yx[px] = all_valid || ((ey >= p.vlo[1]) && (ey < p.vhi[1]) && (ex >= p.vlo[2]) && (ex < p.vhi[2]));
+        // rows 1, 2 of an axis-0-separable matrix ignore d
+        in_yx[px] = all_valid || (canonical_inside_axis(p, 1, 0, h0 + j, w0 + kw) && canonical_inside_axis(p, 2, 0, h0 + j, w0 + kw));
         ooff[px] = (int64_t)(h0 + j) * orow + (w0 + kw);
     }
 

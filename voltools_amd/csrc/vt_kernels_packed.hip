@@ -150,8 +150,8 @@ __global__ __launch_bounds__(256) void affine_tiled_packed(const float* __restri
             base[r] = fma(p.m[4 * r], (double)d0, fma(p.m[4 * r + 1], (double)h0, fma(p.m[4 * r + 2], (double)w0, p.m[4 * r + 3])));
             lo[r] = base[r] + p.neg[r];
             hi[r] = base[r] + p.pos[r];
-            any_valid = any_valid && (hi[r] >= p.vlo[r]) && (lo[r] < p.vhi[r]);
-            all_valid = all_valid && (lo[r] >= p.vlo[r]) && (hi[r] < p.vhi[r]);
+            any_valid = any_valid && (hi[r] >= p.vlo[r] - kTileMargin) && (lo[r] < p.vhi[r] + kTileMargin);
+            all_valid = all_valid && (lo[r] >= p.vlo[r] + kTileMargin) && (hi[r] < p.vhi[r] - kTileMargin);
         }
         if (!any_valid) {
             if (!keep) {
@@ -206,10 +206,6 @@ __global__ __launch_bounds__(256) void affine_tiled_packed(const float* __restri
                     const double s1 = fma(p.m[5], (double)j, fma(p.m[6], (double)kw, b[1]));
                     const double s2 = fma(p.m[9], (double)j, fma(p.m[10], (double)kw, b[2]));
                     Fx c0 = to_fx(s0), c1 = to_fx(s1), c2 = to_fx(s2);
-                    double e0 = s0, e1 = s1, e2 = s2;
-                    const double vlo0 = p.vlo[0] - (double)o[0], vhi0 = p.vhi[0] - (double)o[0];
-                    const double vlo1 = p.vlo[1] - (double)o[1], vhi1 = p.vhi[1] - (double)o[1];
-                    const double vlo2 = p.vlo[2] - (double)o[2], vhi2 = p.vhi[2] - (double)o[2];
                     float* optr = out + ((int64_t)d0 * p.oH + h) * p.oW + w;
                     for (int i = 0; i < nd; ++i) {
                         const int iz = c0.hi, iy = c1.hi, ix = c2.hi;
@@ -250,13 +246,12 @@ __global__ __launch_bounds__(256) void affine_tiled_packed(const float* __restri
                                 val = fmaf(wz[c], accy, val);
                             }
                         }
-                        const bool inside = all_valid || ((e0 >= vlo0) && (e0 < vhi0) && (e1 >= vlo1) && (e1 < vhi1) && (e2 >= vlo2) && (e2 < vhi2));
+                        const bool inside = all_valid || canonical_inside(p, d0 + i, h, w);
                         if (inside) optr[i * ostride] = val;
                         else if (!keep) optr[i * ostride] = 0.0f;
                         fx_step(c0, p.inc_hi[0], p.inc_lo[0]);
                         fx_step(c1, p.inc_hi[1], p.inc_lo[1]);
                         fx_step(c2, p.inc_hi[2], p.inc_lo[2]);
-                        e0 += p.m[0]; e1 += p.m[4]; e2 += p.m[8];
                     }
                 }
                 __syncthreads();                                  // the buffer is restaged by the next tile
@@ -270,12 +265,9 @@ __global__ __launch_bounds__(256) void affine_tiled_packed(const float* __restri
                     for (int i = 0; i < nd; ++i) {
                         const int d = d0 + i;
                         double s[3];
-                        bool inside = true;
 #pragma unroll
-                        for (int r = 0; r < 3; ++r) {
-                            s[r] = fma(p.m[4 * r], (double)d, fma(p.m[4 * r + 1], (double)h, fma(p.m[4 * r + 2], (double)w, p.m[4 * r + 3])));
-                            inside = inside && (s[r] >= p.vlo[r]) && (s[r] < p.vhi[r]);
-                        }
+                        for (int r = 0; r < 3; ++r) s[r] = canonical_coord(p, r, d, h, w);
+                        const bool inside = canonical_inside(p, d, h, w);
                         float* optr = out + ((int64_t)d * p.oH + h) * p.oW + w;
                         if (inside) {
                             const double fzd = floor(s[0]), fyd = floor(s[1]), fxd = floor(s[2]);
