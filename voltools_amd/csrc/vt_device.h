@@ -101,6 +101,66 @@ __device__ __forceinline__ void fx_step(Fx& c, int inc_hi, unsigned inc_lo)
 
 __device__ __forceinline__ float fx_frac(const Fx& c) { return (float)c.lo * 0x1p-32f; }
 
+
+// ---------------------------------------------------------------------------------------------------
+// cubic gather from an LDS image: 16 rows x 4 x-taps with 8-byte reads
+// ---------------------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// The four x taps [ix-1, ix+2] of a row are fetched as three 8-byte-aligned ds_read_b64 (256 B/clk/CU) instead of four
+// ds_read_b32 (128 B/clk/CU): with x1 = ix-1, par = x1 & 1, e = x1 - par, the taps sit at e+par .. e+par+3 of the six loaded
+// values, and meet the weights shifted by the parity.  When par = 0 the third pair is not needed and re-reads the second
+// one (weight 0), so nothing outside the row is touched.  `row(c, bb)` returns the LDS byte address of column e of tap
+// row (z tap c, y tap bb); rows must start 8-byte aligned.  Inline asm: hipcc would fuse the adjacent 8-byte loads into
+// ds_read2_b64 (half the bytes per LDS cycle).  Two z planes of taps are in flight: the wait for plane c leaves the 12
+// reads of plane c+1 outstanding.  [measured: 384^3 cubic general rotation 0.75 -> 0.57 ms]
+template <typename RowAddr>
+__device__ __forceinline__ float cubic_gather_b64(RowAddr row, int par, const float (&wx)[4], const float (&wy)[4], const float (&wz)[4])
+{
+    const float w6[5] = {par ? 0.f : wx[0], par ? wx[0] : wx[1], par ? wx[1] : wx[2], par ? wx[2] : wx[3], par ? wx[3] : 0.f};
+    const unsigned off3 = par ? 16u : 8u;                          // bytes: third pair, or the second one again
+    v2f t[2][12];
+    auto issue = [&](int c, v2f (&r)[12]) {
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            const unsigned ra = row(c, bb);
+            asm volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:8\n\tds_read_b64 %2, %4"
+                         : "=&v"(r[3 * bb]), "=&v"(r[3 * bb + 1]), "=&v"(r[3 * bb + 2]) : "v"(ra), "v"(ra + off3));
+        }
+    };
+    issue(0, t[0]);
+    float val = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        v2f (&r)[12] = t[c & 1];
+        if (c < 3) {
+            issue(c + 1, t[(c + 1) & 1]);
+            asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]),
+                         "+v"(r[7]), "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]));
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]),
+                         "+v"(r[7]), "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]));
+        }
+        float accy = 0.f;
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            float accx = w6[0] * r[3 * bb].x;
+            accx = fmaf(w6[1], r[3 * bb].y, accx);
+            accx = fmaf(w6[2], r[3 * bb + 1].x, accx);
+            accx = fmaf(w6[3], r[3 * bb + 1].y, accx);
+            accx = fmaf(w6[4], r[3 * bb + 2].x, accx);           // par = 0: w6[4] = 0 and the pair is the second one again
+            accy = fmaf(wy[bb], accx, accy);
+        }
+        val = fmaf(wz[c], accy, val);
+    }
+    return val;
+}
+
+__device__ __forceinline__ unsigned lds_byte_address(const float* p)
+{
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) float*)p;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // the skirt rule, one definition for every kernel
 // ---------------------------------------------------------------------------------------------------

@@ -80,6 +80,12 @@ __device__ __forceinline__ float sample_box(const float* __restrict__ lds, int L
         cubic_weights<KIND == 2>(fx, wx);
         cubic_weights<KIND == 2>(fy, wy);
         cubic_weights<KIND == 2>(fz, wz);
+#ifndef VT_CUBIC_B32
+        const int x1 = ix - 1, par = x1 & 1, e = x1 - par;
+        const unsigned qa = lds_byte_address(lds + (__mul24(iz - 1, LyLx) + __mul24(iy - 1, Lx) + e));
+        const unsigned row_b = 4u * (unsigned)Lx, plane_b = 4u * (unsigned)LyLx;
+        return cubic_gather_b64([&](int c, int bb) { return qa + (unsigned)c * plane_b + (unsigned)bb * row_b; }, par, wx, wy, wz);
+#else
         const float* q = lds + (__mul24(iz - 1, LyLx) + __mul24(iy - 1, Lx) + (ix - 1));
         float val = 0.f;
 #pragma unroll
@@ -97,6 +103,7 @@ __device__ __forceinline__ float sample_box(const float* __restrict__ lds, int L
             val = fmaf(wz[c], accy, val);
         }
         return val;
+#endif
     }
 }
 

@@ -173,6 +173,7 @@ __global__ __launch_bounds__(256) void affine_tiled_packed(const float* __restri
 #pragma unroll
             for (int r = 0; r < 3; ++r) b[r] = base[r] - (double)o[r];
 
+            const unsigned buf_addr0 = lds_byte_address(buf);
             if (fits) {
                 // stage the packed footprint
                 const bool box_inside = o[0] >= 0 && o[1] >= 0 && o[2] >= 0 && o[0] + Lz <= p.sD && o[1] + Ly <= p.sH &&
@@ -229,22 +230,16 @@ __global__ __launch_bounds__(256) void affine_tiled_packed(const float* __restri
                             cubic_weights<KIND == 2>(fx, wx);
                             cubic_weights<KIND == 2>(fy, wy);
                             cubic_weights<KIND == 2>(fz, wz);
+                            // rows of the packed image start at multiples of 4 floats, so column e is 8-byte aligned
                             const int* tr = rowbase + (__mul24(iz - 1, Ly) + (iy - 1));
-                            val = 0.f;
+                            const int x1 = ix - 1, par = x1 & 1, e = x1 - par;
+                            const unsigned ba = buf_addr0 + 4u * (unsigned)e;
+                            int roff[16];
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) {
-                                float accy = 0.f;
+                            for (int c = 0; c < 4; ++c)
 #pragma unroll
-                                for (int bb = 0; bb < 4; ++bb) {
-                                    const float* rowp = buf + tr[c * Ly + bb] + (ix - 1);
-                                    float accx = wx[0] * rowp[0];
-                                    accx = fmaf(wx[1], rowp[1], accx);
-                                    accx = fmaf(wx[2], rowp[2], accx);
-                                    accx = fmaf(wx[3], rowp[3], accx);
-                                    accy = fmaf(wy[bb], accx, accy);
-                                }
-                                val = fmaf(wz[c], accy, val);
-                            }
+                                for (int bb = 0; bb < 4; ++bb) roff[4 * c + bb] = tr[c * Ly + bb];
+                            val = cubic_gather_b64([&](int c, int bb) { return ba + 4u * (unsigned)roff[4 * c + bb]; }, par, wx, wy, wz);
                         }
                         const bool inside = all_valid || canonical_inside(p, d0 + i, h, w);
                         if (inside) optr[i * ostride] = val;
