@@ -27,7 +27,9 @@ sys.path.insert(0, ROOT)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=60)
+    # default: the README sweep, `for i in range(180): rotate((0, i, 0))` (README.md:25-27) -- one full set of angles; the
+    # per-angle time varies by +-10 % (footprint shape), so a shorter sweep depends on where it starts
+    ap.add_argument('--steps', type=int, default=180)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--interp', default='filt_bspline')

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 root=$(pwd)
 out=$root/gpurun_out/profiles_$tag
 rm -rf $out; mkdir -p $out
-args="--steps 40 --warmup 5 --no-cpu-baseline"
+args="--steps 180 --warmup 5 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py $args > $out/bench_under_trace.json 2> $out/trace.log
 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_fetch -- python3 bench.py $args > /dev/null 2> $out/pmc_fetch.log
 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/pmc_write -- python3 bench.py $args > /dev/null 2> $out/pmc_write.log
