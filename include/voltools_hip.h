@@ -53,7 +53,8 @@ enum vt_flags {
     VT_NO_ZPAIR = 64,      /* diagnostic: cubic marching on the plain layout instead of the plane-pair copy          */
     VT_NO_PACKED = 128,    /* diagnostic: general matrices use bounding-box tiles, not packed footprints             */
     VT_FORCE_PACKED = 256, /* diagnostic: packed footprints whenever they fit, even where boxes are cheaper          */
-    VT_FORCE_XSWAP = 512   /* diagnostic: rotations about axis 2 take the axis-exchange path for every interpolation  */
+    VT_FORCE_XSWAP = 512,  /* diagnostic: rotations about axis 2 take the axis-exchange path for every interpolation  */
+    VT_NO_RSWAP = 1024     /* diagnostic: in-plane maps near a quarter turn sample the plain copy, not the transposed */
 };
 
 /* flags for vt_volume_create* */

@@ -34,6 +34,8 @@ MATRICES = {
     'shift_int': lambda s: vt.utils.translation_matrix((3, -2, 5)),
     'shift_frac': lambda s: vt.utils.translation_matrix((0.5, -1.25, 2.75)),
     'rot_inplane45': lambda s: vt.utils.transform_matrix(rotation=(0, 45, 0), center=centre(s)),
+    'rot_inplane100': lambda s: vt.utils.transform_matrix(rotation=(0, 100, 0), translation=(0.5, -1.25, 2.0), center=centre(s)),
+    'rot_inplane260': lambda s: vt.utils.transform_matrix(rotation=(0, 260, 0), center=centre(s)),
     'rot_general': lambda s: vt.utils.transform_matrix(rotation=(25, -40, 70), rotation_order='sxyz', center=centre(s)),
     'rot_scale_shift': lambda s: vt.utils.transform_matrix(rotation=(10, 20, 30), scale=(1.1, 0.9, 1.25),
                                                            translation=(1.5, -2.0, 0.75), center=centre(s)),
@@ -74,7 +76,7 @@ def test_tiled_and_direct_match_oracle(interp, mname, shape):
     want = oracle.affine(vol, m, interp)
     kernels = set()
     for flags in (_native.FORCE_TILED | _native.FORCE_XSWAP, _native.FORCE_TILED | _native.FORCE_XSWAP | _native.NO_ZPAIR,
-                  _native.FORCE_TILED, _native.FORCE_TILED | _native.NO_MARCH,
+                  _native.FORCE_TILED, _native.FORCE_TILED | _native.NO_RSWAP, _native.FORCE_TILED | _native.NO_MARCH,
                   _native.FORCE_TILED | _native.NO_ZSEP | _native.FORCE_PACKED, _native.FORCE_TILED | _native.NO_ZSEP | _native.NO_PACKED,
                   _native.FORCE_DIRECT):
         got, info = run_case(vol, m, interp, flags)
@@ -84,7 +86,7 @@ def test_tiled_and_direct_match_oracle(interp, mname, shape):
     if mname in ('rot_axis1', 'rot_axis1_shift', 'rot_axis2', 'rot_axis2_shift'):
         # rotations about axis 1 / 2 march along an axis-exchanged resident copy
         assert (4 in kernels) if interp == 'linear' else (5 in kernels and 4 in kernels)
-    if mname in ('identity', 'shift_int', 'shift_frac', 'rot_inplane45'):
+    if mname in ('identity', 'shift_int', 'shift_frac', 'rot_inplane45', 'rot_inplane100', 'rot_inplane260'):
         assert 3 in kernels and 4 in kernels         # both axis-0-separable kernels were exercised
         assert (5 in kernels) == (interp != 'linear')   # cubic: the plane-pair marching kernel too
     if mname not in ('minify_big', 'far_outside'):

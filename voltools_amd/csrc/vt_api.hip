@@ -77,6 +77,9 @@ struct vt_volume {
     float* d_src_zp = nullptr;         // second resident copy, planes interleaved in pairs (cubic marching kernel); lazy
     float* d_src_t = nullptr;          // resident copy with axes 0 and 1 exchanged (rotations about axis 1 march along it); lazy
     float* d_src_t_zp = nullptr;       // ... and its plane-pair form; lazy
+    float* d_src_r = nullptr;          // resident copy transposed in-plane ([z][x][y], pitch Pr; quarter-turn class of in-plane maps); lazy
+    float* d_src_r_zp = nullptr;       // ... and its plane-pair form; lazy
+    int Pr = 0;
     float* d_src_x = nullptr;          // resident copy with axes 0 and 2 exchanged ([x][y][z], pitch Px; rotations about axis 2); lazy
     float* d_src_x_zp = nullptr;       // ... and its plane-pair form; lazy
     int Px = 0;
@@ -720,6 +723,48 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
             xswap = true;
         }
     }
+    // In-plane maps closer to a quarter turn than to the identity (|m12| > |m11|: rotations about axis 0 by 45..135 and
+    // 225..315 degrees): sampled from an in-plane TRANSPOSED resident copy the same map has its rows 1 and 2 exchanged and
+    // falls into the 0..45 degree class, whose footprints are wide in x (long staged rows, lanes walk along LDS rows
+    // instead of down a column).  Only the source side changes; the output is written as usual.
+    const bool zsep_m = m[0] == 1.0 && m[1] == 0.0 && m[2] == 0.0 && m[4] == 0.0 && m[8] == 0.0 && std::fabs(m[3]) < 1.0e9;
+    const bool rsep = plan.kind == 0 && zsep_m && !(flags & (VT_NO_ZSEP | VT_NO_MARCH | VT_FORCE_DIRECT | VT_NO_RSWAP)) &&
+                      std::fabs(m[6]) > std::fabs(m[5]) && std::fabs(m[9]) > std::fabs(m[10]) && v->D <= 65535 &&
+                      (n_out >= (size_t)64 * 64 * 64 || (flags & VT_FORCE_TILED));
+    if (rsep) {
+        vt_volume sw;
+        sw.dev = v->dev; sw.interp = v->interp;
+        sw.D = v->D; sw.H = v->W; sw.W = v->H; sw.P = ((v->H + 3) & ~3) + 4;
+        sw.oD = v->oD; sw.oH = v->oH; sw.oW = v->oW;
+        sw.plane0 = v->plane0; sw.gD = v->gD; sw.out_plane0 = v->out_plane0;
+        sw.lds_limit = v->lds_limit; sw.cu_count = v->cu_count; sw.force_cfg = v->force_cfg; sw.force_la = v->force_la;
+        double ms[12];
+        for (int c = 0; c < 4; ++c) { ms[c] = m[c]; ms[4 + c] = m[8 + c]; ms[8 + c] = m[4 + c]; }
+        AffineParams ps;
+        std::memset(&ps, 0, sizeof(ps));
+        TilePlan plans;
+        rc = plan_launch(&sw, ms, flags, &ps, &plans);
+        if (rc) return rc;
+        if ((plans.kind == 4 || plans.kind == 5) && !v->d_src_r) {
+            v->Pr = sw.P;
+            const size_t bytes = (size_t)v->D * v->W * v->Pr * sizeof(float);
+            if (hipMalloc(reinterpret_cast<void**>(&v->d_src_r), bytes) != hipSuccess) {
+                (void)hipGetLastError();          // no room for another copy: the plain layout serves this matrix
+                v->d_src_r = nullptr;
+                plans.kind = 0;
+            } else {
+                VT_HIP(hipMemsetAsync(v->d_src_r, 0, bytes, v->stream));          // pad columns must be zero
+                // dst[x][z][y] in (k, j, i) terms: element (i = y, j = z, k = x) -> (k = x, j = z, i = y)
+                VT_HIP(launch_transpose02(v->d_src, v->d_src_r, v->H, v->D, v->W, v->P, (int64_t)v->H * v->P,
+                                          v->Pr, (int64_t)v->W * v->Pr, v->stream));
+            }
+        }
+        if (plans.kind == 4 || plans.kind == 5) {
+            p = ps; plan = plans;
+            src_plain = v->d_src_r; pair_slot = &v->d_src_r_zp;
+            srcD = v->D; srcH = v->W; pair_W = v->H; pair_P = v->Pr;
+        }
+    }
     if (plan.kind == 0) {
         rc = plan_launch(v, m, flags, &p, &plan);
         if (rc) return rc;
@@ -1207,6 +1252,8 @@ int vt_volume_destroy(vt_volume_t* v)
     if (v->d_src_t) hipFree(v->d_src_t);
     if (v->d_src_t_zp) hipFree(v->d_src_t_zp);
     if (v->d_src_x) hipFree(v->d_src_x);
+    if (v->d_src_r) hipFree(v->d_src_r);
+    if (v->d_src_r_zp) hipFree(v->d_src_r_zp);
     if (v->d_src_x_zp) hipFree(v->d_src_x_zp);
     if (v->d_tmp_x) hipFree(v->d_tmp_x);
     if (v->d_scratch_out) hipFree(v->d_scratch_out);
