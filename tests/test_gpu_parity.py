@@ -325,6 +325,33 @@ def test_affine_batch_matches_single_calls(interp):
         sv.close()
 
 
+@pytest.mark.parametrize('interp', ['linear', 'filt_bspline'])
+def test_oneshot_matches_resident_path(interp):
+    """transform() on a host volume (vt_affine_oneshot: upload, prefilter, transform, download) against the resident
+    StaticVolume path, which the other tests pin to the oracle; volume above the pinning threshold, results from the pool."""
+    shape = (256, 192, 320)                       # 63 MB
+    vol = rand_vol(shape, 21)
+    sv = vt.StaticVolume(vol, interpolation=interp, device='gpu:0')
+    tol = 0.0                                     # same kernels on the same data
+    cases = [vt.utils.transform_matrix(rotation=(0, 33, 0), translation=(2.5, 1.0, -3.0), center=centre(shape)),
+             vt.utils.translation_matrix((-7.25, 0.5, 0.0)),
+             np.eye(4, dtype=np.float32),
+             vt.utils.transform_matrix(rotation=(0, 100, 0), scale=(1.0, 1.2, 0.8), center=centre(shape)),
+             vt.utils.transform_matrix(rotation=(25, -40, 70), rotation_order='sxyz', center=centre(shape)),
+             vt.utils.translation_matrix((300.0, 0, 0))]
+    for i, m in enumerate(cases):
+        want = sv.affine(m)
+        got = vt.affine(vol, m, interpolation=interp, device='gpu')
+        assert got.shape == shape
+        assert np.abs(got - want).max() <= tol, (interp, i, float(np.abs(got - want).max()))
+    # caller-supplied host output, and the reference's outside-voxel behaviour
+    m = cases[0]
+    out = np.full(shape, 7.0, dtype=np.float32)
+    assert vt.affine(vol, m, interpolation=interp, device='gpu', output=out) is None
+    assert np.abs(out - sv.affine(m)).max() <= tol
+    sv.close()
+
+
 @pytest.mark.parametrize('interp', ['linear', 'bspline'])
 def test_projection_repeated_calls_large_plane(interp):
     """A plane large enough for the tiled kernels; successive projections must not see stale helper state."""
