@@ -494,6 +494,10 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
                 if (v->force_cfg >= 0 && c != v->force_cfg) continue;
                 int T[3];
                 packed_config(c, &T[0], &T[1], &T[2]);
+                // too few tiles to amortise the per-workgroup set-up (see `enough` below): do not even plan it -- the span
+                // summation below is the most expensive part of the host-side planning (~20 us)
+                const int64_t tiles_c = (int64_t)((v->oD + T[0] - 1) / T[0]) * ((v->oH + T[1] - 1) / T[1]) * ((v->oW + T[2] - 1) / T[2]);
+                if (!(flags & VT_FORCE_PACKED) && tiles_c < 6 * (int64_t)v->cu_count * (cubic ? 2 : 3)) continue;
                 PackGeom g;
                 int L[3];
                 bool ok = true;
