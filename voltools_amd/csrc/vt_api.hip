@@ -45,13 +45,27 @@ int use_device(int dev)
 
 std::once_flag g_init_flag[64];
 hipError_t g_init_err[64];
+// per-device constants, fetched once (hipGetDeviceProperties and a hipMalloc per handle were a visible part of the
+// ~0.4 ms a one-shot transform of a tiny volume costs)
+int g_cu_count[64], g_lds_limit[64];
+float* g_zeros[64];                // 256 bytes of zeros per device: the border fetch target of the tiled kernels (never freed)
 
 int init_device(int dev)
 {
     int rc = use_device(dev);
     if (rc) return rc;
     if (dev < 64) {
-        std::call_once(g_init_flag[dev], [dev]() { g_init_err[dev] = init_affine_kernels(); });
+        std::call_once(g_init_flag[dev], [dev]() {
+            g_init_err[dev] = init_affine_kernels();
+            hipDeviceProp_t prop;
+            if (g_init_err[dev] == hipSuccess) g_init_err[dev] = hipGetDeviceProperties(&prop, dev);
+            if (g_init_err[dev] == hipSuccess) {
+                g_cu_count[dev] = prop.multiProcessorCount;
+                g_lds_limit[dev] = (int)std::min<size_t>(160 * 1024, prop.sharedMemPerBlock > 0 ? prop.sharedMemPerBlock : 65536);
+                g_init_err[dev] = hipMalloc(reinterpret_cast<void**>(&g_zeros[dev]), 256);
+            }
+            if (g_init_err[dev] == hipSuccess) g_init_err[dev] = hipMemset(g_zeros[dev], 0, 256);
+        });
         if (g_init_err[dev] != hipSuccess)
             return fail((int)g_init_err[dev], "kernel attribute setup failed: %s", hipGetErrorString(g_init_err[dev]));
     }
@@ -871,11 +885,13 @@ int create_common(int dev, int D, int H, int W, int interp, const float* data, i
         vt_volume_destroy(v);
         return code;
     };
-    hipDeviceProp_t prop;
-    hipError_t e = hipGetDeviceProperties(&prop, dev);
-    if (e != hipSuccess) return cleanup(fail((int)e, "hipGetDeviceProperties: %s", hipGetErrorString(e)));
-    v->cu_count = prop.multiProcessorCount;
-    v->lds_limit = (int)std::min<size_t>(160 * 1024, prop.sharedMemPerBlock > 0 ? prop.sharedMemPerBlock : 65536);
+    if (dev < 64) {
+        v->cu_count = g_cu_count[dev];
+        v->lds_limit = g_lds_limit[dev];
+        v->d_zeros = g_zeros[dev];
+    } else {
+        return cleanup(fail(VT_ENODEV, "device index %d beyond the supported 64", dev));
+    }
 
 #define VT_HIPC(call)                                                                                     \
     do {                                                                                                  \
@@ -894,8 +910,6 @@ int create_common(int dev, int D, int H, int W, int interp, const float* data, i
     v->P = ((W + 3) & ~3) + 4;         // + one guaranteed zero vector per row (border fetch target)
     const size_t bytes = (size_t)D * H * v->P * sizeof(float);
     VT_HIPC(hipMalloc(reinterpret_cast<void**>(&v->d_src), bytes));
-    VT_HIPC(hipMalloc(reinterpret_cast<void**>(&v->d_zeros), 256));
-    VT_HIPC(hipMemsetAsync(v->d_zeros, 0, 256, v->stream));
     const hipMemcpyKind kind = (cflags & VT_SRC_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     if (cflags & kSrcNone) {
         // internal helper volumes: zero-filled, written by a kernel later
@@ -1251,7 +1265,6 @@ int vt_volume_destroy(vt_volume_t* v)
     hipSetDevice(v->dev);
     if (v->stream) hipStreamSynchronize(v->stream);
     if (v->d_src) hipFree(v->d_src);
-    if (v->d_zeros) hipFree(v->d_zeros);
     if (v->d_src_zp) hipFree(v->d_src_zp);
     if (v->d_src_t) hipFree(v->d_src_t);
     if (v->d_src_t_zp) hipFree(v->d_src_t_zp);
