@@ -8,7 +8,7 @@ def t(fn, reps=7):
     for _ in range(reps):
         t0 = time.perf_counter(); r = fn(); best = min(best, time.perf_counter() - t0); del r
     return best * 1e3
-for n in (250, 512):
+for n in [int(x) for x in os.environ.get("ONESHOT_SIZES", "250,512").split(",")]:
     data = np.random.RandomState(1).random_sample((n, n, n)).astype(np.float32)
     m = vt.utils.transform_matrix(rotation=(10, 20, 30), rotation_order='sxyz', center=np.divide((n, n, n), 2))
     for interp in ('linear', 'filt_bspline'):

@@ -50,6 +50,86 @@ hipError_t g_init_err[64];
 int g_cu_count[64], g_lds_limit[64];
 float* g_zeros[64];                // 256 bytes of zeros per device: the border fetch target of the tiled kernels (never freed)
 
+
+// ---------------------------------------------------------------------------------------------------
+// Per-device recycling of what a handle's life costs besides the copies: a HIP stream, two events and small device buffers.
+// A one-shot transform() of a tiny volume spent 0.38 of its 0.43 ms creating and destroying these
+// (tools/oneshot_breakdown.py).  Streams and events go back to a free list when a handle is destroyed (it synchronises
+// first); device buffers up to 64 MiB are kept by exact size, at most 16 of them and 256 MiB in total per device.
+// ---------------------------------------------------------------------------------------------------
+struct DeviceCache {
+    std::mutex mu;
+    std::vector<hipStream_t> streams;
+    std::vector<hipEvent_t> events;
+    std::vector<std::pair<size_t, void*>> bufs;
+    size_t buf_bytes = 0;
+};
+DeviceCache g_cache[64];
+constexpr size_t kCacheBufMax = (size_t)64 << 20, kCacheTotalMax = (size_t)256 << 20;
+
+hipError_t cached_stream(int dev, hipStream_t* s)
+{
+    if (dev < 64) {
+        std::lock_guard<std::mutex> lk(g_cache[dev].mu);
+        if (!g_cache[dev].streams.empty()) { *s = g_cache[dev].streams.back(); g_cache[dev].streams.pop_back(); return hipSuccess; }
+    }
+    // a blocking stream: ordered against the legacy null stream (torch's default), like the reference, which does
+    // everything on cupy's null stream (transforms.py:168, volume.py:66)
+    return hipStreamCreateWithFlags(s, hipStreamDefault);
+}
+void recycle_stream(int dev, hipStream_t s)
+{
+    if (dev < 64) {
+        std::lock_guard<std::mutex> lk(g_cache[dev].mu);
+        if (g_cache[dev].streams.size() < 8) { g_cache[dev].streams.push_back(s); return; }
+    }
+    (void)hipStreamDestroy(s);
+}
+hipError_t cached_event(int dev, hipEvent_t* e)
+{
+    if (dev < 64) {
+        std::lock_guard<std::mutex> lk(g_cache[dev].mu);
+        if (!g_cache[dev].events.empty()) { *e = g_cache[dev].events.back(); g_cache[dev].events.pop_back(); return hipSuccess; }
+    }
+    return hipEventCreate(e);
+}
+void recycle_event(int dev, hipEvent_t e)
+{
+    if (dev < 64) {
+        std::lock_guard<std::mutex> lk(g_cache[dev].mu);
+        if (g_cache[dev].events.size() < 16) { g_cache[dev].events.push_back(e); return; }
+    }
+    (void)hipEventDestroy(e);
+}
+hipError_t cached_malloc(int dev, void** p, size_t bytes)
+{
+    if (dev < 64 && bytes <= kCacheBufMax) {
+        std::lock_guard<std::mutex> lk(g_cache[dev].mu);
+        auto& b = g_cache[dev].bufs;
+        for (size_t i = 0; i < b.size(); ++i)
+            if (b[i].first == bytes) {
+                *p = b[i].second;
+                g_cache[dev].buf_bytes -= bytes;
+                b.erase(b.begin() + (long)i);
+                return hipSuccess;
+            }
+    }
+    return hipMalloc(p, bytes);
+}
+void cached_free(int dev, void* p, size_t bytes)
+{
+    if (!p) return;
+    if (dev < 64 && bytes <= kCacheBufMax) {
+        std::lock_guard<std::mutex> lk(g_cache[dev].mu);
+        if (g_cache[dev].bufs.size() < 16 && g_cache[dev].buf_bytes + bytes <= kCacheTotalMax) {
+            g_cache[dev].bufs.emplace_back(bytes, p);
+            g_cache[dev].buf_bytes += bytes;
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
+
 int init_device(int dev)
 {
     int rc = use_device(dev);
@@ -87,6 +167,7 @@ struct vt_volume {
     int64_t out_plane0 = 0;            // global index of output plane 0
     int P = 0;                         // row pitch of d_src in floats: W rounded up to 4, pad columns hold 0
     float* d_src = nullptr;
+    size_t src_bytes = 0;              // size of the d_src allocation (small ones are recycled per device)
     float* d_zeros = nullptr;          // 16 bytes of zeros: the border fetch target of the tiled kernel
     float* d_src_zp = nullptr;         // second resident copy, planes interleaved in pairs (cubic marching kernel); lazy
     float* d_src_t = nullptr;          // resident copy with axes 0 and 1 exchanged (rotations about axis 1 march along it); lazy
@@ -792,8 +873,8 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
     const bool host_out = !(flags & VT_OUT_DEVICE);
     if (host_out) {
         if (v->scratch_elems < n_out) {
-            if (v->d_scratch_out) { VT_HIP(hipFree(v->d_scratch_out)); v->d_scratch_out = nullptr; v->scratch_elems = 0; }
-            VT_HIP(hipMalloc(reinterpret_cast<void**>(&v->d_scratch_out), n_out * sizeof(float)));
+            if (v->d_scratch_out) { cached_free(v->dev, v->d_scratch_out, v->scratch_elems * sizeof(float)); v->d_scratch_out = nullptr; v->scratch_elems = 0; }
+            VT_HIP(cached_malloc(v->dev, reinterpret_cast<void**>(&v->d_scratch_out), n_out * sizeof(float)));
             v->scratch_elems = n_out;
         }
         d_out = v->d_scratch_out;
@@ -900,16 +981,15 @@ int create_common(int dev, int D, int H, int W, int interp, const float* data, i
             return cleanup(fail((int)e_, "%s: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__)); \
     } while (0)
 
-    // a blocking stream: ordered against the legacy null stream (torch's default), like the reference,
-    // which does everything on cupy's null stream (transforms.py:168, volume.py:66)
-    VT_HIPC(hipStreamCreateWithFlags(&v->stream, hipStreamDefault));
-    VT_HIPC(hipEventCreate(&v->ev0));
-    VT_HIPC(hipEventCreate(&v->ev1));
+    VT_HIPC(cached_stream(dev, &v->stream));      // blocking stream (see cached_stream)
+    VT_HIPC(cached_event(dev, &v->ev0));
+    VT_HIPC(cached_event(dev, &v->ev1));
     // resident layout: rows padded to a multiple of 4 floats so every row starts 16-byte aligned (the tiled
     // kernel stages with 16-byte direct-to-LDS loads); pad columns are zero = the border value
     v->P = ((W + 3) & ~3) + 4;         // + one guaranteed zero vector per row (border fetch target)
     const size_t bytes = (size_t)D * H * v->P * sizeof(float);
-    VT_HIPC(hipMalloc(reinterpret_cast<void**>(&v->d_src), bytes));
+    VT_HIPC(cached_malloc(dev, reinterpret_cast<void**>(&v->d_src), bytes));
+    v->src_bytes = bytes;
     const hipMemcpyKind kind = (cflags & VT_SRC_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     if (cflags & kSrcNone) {
         // internal helper volumes: zero-filled, written by a kernel later
@@ -929,10 +1009,10 @@ int create_common(int dev, int D, int H, int W, int interp, const float* data, i
 
     if (is_filtered(interp)) {
         float* d_tmp = nullptr;
-        VT_HIPC(hipMalloc(reinterpret_cast<void**>(&d_tmp), bytes));
+        VT_HIPC(cached_malloc(dev, reinterpret_cast<void**>(&d_tmp), bytes));
         {
             hipError_t em = hipMemset2DAsync(d_tmp + W, (size_t)v->P * sizeof(float), 0, (size_t)(v->P - W) * sizeof(float), (size_t)D * H, v->stream);
-            if (em != hipSuccess) { hipFree(d_tmp); return cleanup(fail((int)em, "memset: %s", hipGetErrorString(em))); }
+            if (em != hipSuccess) { cached_free(dev, d_tmp, bytes); return cleanup(fail((int)em, "memset: %s", hipGetErrorString(em))); }
         }
         float* res = nullptr;
         hipEventRecord(v->ev0, v->stream);
@@ -940,13 +1020,13 @@ int create_common(int dev, int D, int H, int W, int interp, const float* data, i
         hipEventRecord(v->ev1, v->stream);
         hipError_t es = hipStreamSynchronize(v->stream);
         if (rc || es != hipSuccess) {
-            hipFree(d_tmp);
+            cached_free(dev, d_tmp, bytes);
             if (!rc) rc = fail((int)es, "prefilter: %s", hipGetErrorString(es));
             return cleanup(rc);
         }
         hipEventElapsedTime(&v->prefilter_ms, v->ev0, v->ev1);
-        if (res == d_tmp) { hipFree(v->d_src); v->d_src = d_tmp; }
-        else hipFree(d_tmp);
+        if (res == d_tmp) { cached_free(dev, v->d_src, bytes); v->d_src = d_tmp; }
+        else cached_free(dev, d_tmp, bytes);
     } else {
         VT_HIPC(hipStreamSynchronize(v->stream));
     }
@@ -1004,8 +1084,8 @@ int do_affine_batch(vt_volume* v, int n, const double* m4x4s, float* out, int fl
     const size_t total = n_out * (size_t)n;
     if (host_out) {
         if (v->scratch_elems < total) {
-            if (v->d_scratch_out) { VT_HIP(hipFree(v->d_scratch_out)); v->d_scratch_out = nullptr; v->scratch_elems = 0; }
-            VT_HIP(hipMalloc(reinterpret_cast<void**>(&v->d_scratch_out), total * sizeof(float)));
+            if (v->d_scratch_out) { cached_free(v->dev, v->d_scratch_out, v->scratch_elems * sizeof(float)); v->d_scratch_out = nullptr; v->scratch_elems = 0; }
+            VT_HIP(cached_malloc(v->dev, reinterpret_cast<void**>(&v->d_scratch_out), total * sizeof(float)));
             v->scratch_elems = total;
         }
         d_out = v->d_scratch_out;
@@ -1054,7 +1134,7 @@ int do_project(vt_volume* v, const double m4x4[16], float* out, int flags)
             vt_volume* h = nullptr;
             rc = create_common(v->dev, 3, v->H, v->W, kind, nullptr, kSrcNone, 0, 3, 1, 1, &h);
             if (rc) return rc;
-            hipStreamDestroy(h->stream);         // the helper runs on this handle's stream (ordered after the sum)
+            recycle_stream(h->dev, h->stream);   // the helper runs on this handle's stream (ordered after the sum)
             h->stream = v->stream;
             h->owns_stream = false;
             v->proj = h;
@@ -1105,8 +1185,8 @@ int do_project(vt_volume* v, const double m4x4[16], float* out, int flags)
     float* d_out = out;
     if (host_out) {
         if (v->scratch_elems < n2) {
-            if (v->d_scratch_out) { VT_HIP(hipFree(v->d_scratch_out)); v->d_scratch_out = nullptr; v->scratch_elems = 0; }
-            VT_HIP(hipMalloc(reinterpret_cast<void**>(&v->d_scratch_out), n2 * sizeof(float)));
+            if (v->d_scratch_out) { cached_free(v->dev, v->d_scratch_out, v->scratch_elems * sizeof(float)); v->d_scratch_out = nullptr; v->scratch_elems = 0; }
+            VT_HIP(cached_malloc(v->dev, reinterpret_cast<void**>(&v->d_scratch_out), n2 * sizeof(float)));
             v->scratch_elems = n2;
         }
         d_out = v->d_scratch_out;
@@ -1264,7 +1344,7 @@ int vt_volume_destroy(vt_volume_t* v)
     if (!v) return 0;
     hipSetDevice(v->dev);
     if (v->stream) hipStreamSynchronize(v->stream);
-    if (v->d_src) hipFree(v->d_src);
+    if (v->d_src) cached_free(v->dev, v->d_src, v->src_bytes);
     if (v->d_src_zp) hipFree(v->d_src_zp);
     if (v->d_src_t) hipFree(v->d_src_t);
     if (v->d_src_t_zp) hipFree(v->d_src_t_zp);
@@ -1273,13 +1353,13 @@ int vt_volume_destroy(vt_volume_t* v)
     if (v->d_src_r_zp) hipFree(v->d_src_r_zp);
     if (v->d_src_x_zp) hipFree(v->d_src_x_zp);
     if (v->d_tmp_x) hipFree(v->d_tmp_x);
-    if (v->d_scratch_out) hipFree(v->d_scratch_out);
+    if (v->d_scratch_out) cached_free(v->dev, v->d_scratch_out, v->scratch_elems * sizeof(float));
     if (v->d_proj_tmp) hipFree(v->d_proj_tmp);
     if (v->d_batch_m) hipFree(v->d_batch_m);
     if (v->proj) { vt_volume_destroy(v->proj); v->proj = nullptr; }
-    if (v->ev0) hipEventDestroy(v->ev0);
-    if (v->ev1) hipEventDestroy(v->ev1);
-    if (v->stream && v->owns_stream) hipStreamDestroy(v->stream);
+    if (v->ev0) recycle_event(v->dev, v->ev0);
+    if (v->ev1) recycle_event(v->dev, v->ev1);
+    if (v->stream && v->owns_stream) recycle_stream(v->dev, v->stream);
     delete v;
     return 0;
 }
