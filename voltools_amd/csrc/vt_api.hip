@@ -1486,8 +1486,9 @@ int vt_prefilter_inplace(int dev, float* d_volume, int D, int H, int W)
 // One-shot transform of a host volume into a host buffer (transforms.py:164-226): upload, prefilter, transform, download.
 // PCIe-bound (512^3: 2 x 10 ms of copies around < 1.5 ms of kernels).  A slab pipeline built from slab handles and two host
 // threads (upload of one slab against the download of another) was measured SLOWER (512^3 linear 24.9 vs 20.2 ms, filt 38.5
-// vs 21.9): per-slab hipMalloc/hipFree synchronise the device and serialise the threads.  Duplex overlap needs one resident
-// buffer filled progressively with per-slab launches gated by events -- open.
+// vs 21.9 with hipMalloc/hipFree per slab; 27.2 vs 19.8 and 21.4 vs 21.5 once the slab buffers were recycled): the uploads
+// and downloads of the two threads do not overlap in practice (pitched 2-D uploads, blocking streams).  Duplex overlap needs one
+// resident buffer filled progressively on a copy stream with per-slab launches gated by events -- open.
 int vt_affine_oneshot(int dev, const float* h_volume, int D, int H, int W, int interp, const float* m4x4,
                       float* h_out, int flags, float* elapsed_ms)
 {
