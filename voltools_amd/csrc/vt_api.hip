@@ -366,8 +366,9 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
                 }
                 if (!ok) continue;
                 L[2] = (L[2] + 1 + 1) & ~1;                      // origin aligned down by up to 1 position, even width
-                // box vs packed spans: on par at 512^3, packed 7 % faster at 1024^3 (fabric-bound) [measured]
-                bool zp_box = (int64_t)v->H * v->W <= 512 * 512;
+                // boxes (stride padding fetched from the zero vector) vs packed spans [measured]: 512^3 sweep mean 0.292 vs
+                // 0.312 ms, 1024^3 2.25-2.33 vs 2.28-2.38 ms -> boxes; VT_MARCH_BOX=0 selects packed spans
+                bool zp_box = true;
                 if (const char* e = std::getenv("VT_MARCH_BOX")) zp_box = std::atoi(e) != 0;
                 const int lx_used = L[2];                         // columns that hold data; the rest is stride padding
                 int best_lx = L[2];
