@@ -95,6 +95,22 @@ def test_tiled_and_direct_match_oracle(interp, mname, shape):
         assert 6 in kernels                          # packed-footprint kernel for invertible general matrices
 
 
+@pytest.mark.parametrize('interp', ['linear', 'bspline', 'filt_bspline_simple'])
+@pytest.mark.parametrize('box', ['0', '1'])
+def test_marching_staging_modes(interp, box, monkeypatch):
+    """Both staging modes of both marching kernels (bounding boxes / packed row spans), whichever the planner prefers."""
+    monkeypatch.setenv('VT_MARCH_BOX', box)
+    shape = (70, 66, 72)
+    vol = rand_vol(shape, 5)
+    for mname in ('shift_frac', 'rot_inplane45', 'rot_inplane100', 'rot_axis1_shift', 'rot_axis2_shift'):
+        m = MATRICES[mname](shape)
+        want = oracle.affine(vol, m, interp)
+        for flags in (_native.FORCE_TILED | _native.FORCE_XSWAP, _native.FORCE_TILED | _native.FORCE_XSWAP | _native.NO_ZPAIR):
+            got, info = run_case(vol, m, interp, flags)
+            assert info.last_kernel in (4, 5)
+            assert np.abs(got - want).max() <= TOL[interp], (interp, box, mname, flags)
+
+
 @pytest.mark.parametrize('interp', ['linear', 'bspline', 'filt_bspline'])
 def test_default_dispatch_uses_tiled_kernel_on_large_volumes(interp):
     shape = (96, 100, 104)
