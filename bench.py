@@ -33,6 +33,8 @@ def parse():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--interp', default='filt_bspline')
+    ap.add_argument('--strong', action='store_true', help='strong scaling: ONE size^3 volume cut into axis-0 slabs over the '
+                    'ranks (SURVEY 8d config 5); default is weak scaling, one size^3 slab per rank')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target wall time of the CPU baseline sample')
     return ap.parse_args()
@@ -130,7 +132,11 @@ def main():
     interp = args.interp
 
     # synthetic data: uniform [0,1) float32, seeded per rank
-    vol = np.random.RandomState(rank).random_sample((n, n, n)).astype(np.float32)
+    strong = args.strong and world > 1
+    nd = n // world if strong else n               # planes of this rank's slab
+    if strong and n % world:
+        raise SystemExit('--strong needs size divisible by the number of ranks')
+    vol = np.random.RandomState(rank).random_sample((nd, n, n)).astype(np.float32)
     use_slab = world > 1 or os.environ.get('BENCH_FORCE_SLAB') == '1'
     if use_slab and dist is None:
         import torch.distributed as dist
@@ -142,8 +148,8 @@ def main():
         sv = SlabVolume(vol, interpolation=interp, device=dev, group=dist.group.WORLD)
     else:
         sv = vt.StaticVolume(vol, interpolation=interp, device=dev)
-    out = vt.empty((n, n, n), device=dev)
-    gshape = (n * world, n, n)
+    out = vt.empty((nd, n, n), device=dev)
+    gshape = (nd * world, n, n)
     centre = np.divide(np.subtract(gshape, 1), 2, dtype=np.float32)
     mats = [vt.utils.transform_matrix(rotation=(0, float(i % 180), 0), rotation_units='deg', rotation_order='rzxz',
                                       center=centre) for i in range(args.warmup + args.steps)]
@@ -169,10 +175,10 @@ def main():
         elapsed = float(t.item())
 
     info = sv.info()
-    vox_per_step = n * n * n * world
+    vox_per_step = nd * n * n * world
     value = vox_per_step * args.steps / elapsed / 1e6
     kernel_ms = kernel_ms_total / args.steps
-    algo_bytes = 8.0 * n * n * n                     # 4 B compulsory source read + 4 B store per output voxel
+    algo_bytes = 8.0 * nd * n * n                    # 4 B compulsory source read + 4 B store per output voxel (per rank's launch)
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
     kind_code = {'linear': 0, 'bspline': 1, 'filt_bspline': 1}.get(interp, 2)
     kname = {1: f'vt::affine_direct<{kind_code}>', 2: f'vt::affine_tiled<{kind_code}', 3: f'vt::affine_tiled_zsep<{kind_code}',
@@ -181,10 +187,10 @@ def main():
     result = {
         'metric': 'Mvoxels/s, 512^3 f32 filt_bspline StaticVolume transform (resident source, device output)',
         'value': round(value, 1), 'unit': 'Mvoxels/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
+        'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'strong' if strong else 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': f'{n}^3 float32 {interp}, StaticVolume resident in HBM, rotate((0,i,0)) rzxz sweep, '
-                               f'output= device buffer' + (f', {world} axis-0 slabs of {n}^3' if world > 1 else ''),
+                               f'output= device buffer' + (f', {world} axis-0 slabs of {nd}x{n}x{n}' if world > 1 else ''),
                    'tile': list(info.last_tile), 'lds_bytes': int(info.last_lds_bytes), 'kernel': int(info.last_kernel),
                    'prefilter_ms_once': round(float(info.prefilter_ms), 3)},
         'roofline': {'bound': 'hbm', 'kernel': kname, 'achieved': round(achieved, 1), 'peak': 8000.0,
