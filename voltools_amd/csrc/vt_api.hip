@@ -863,6 +863,7 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
             p = ps; plan = plans;
             src_plain = v->d_src_r; pair_slot = &v->d_src_r_zp;
             srcD = v->D; srcH = v->W; pair_W = v->H; pair_P = v->Pr;
+            if (!std::getenv("VT_RSWAP_WFAST")) p.flags |= (1 << 24);          // h-fastest tile order on the transposed copy
         }
     }
     if (plan.kind == 0) {

@@ -142,10 +142,20 @@ __global__ __launch_bounds__(NT) void affine_march_zsep(const float* __restrict_
 
     const int tid = threadIdx.x;
     const int t = xcd_contiguous(blockIdx.x, gridDim.x);
-    const int tw_i = t % p.nTw;
-    const int t2 = t / p.nTw;
-    const int th_i = t2 % p.nTh;
-    const int chunk = t2 / p.nTh;
+    // tile order inside a chunk: w fastest, or h fastest when the source is the in-plane transposed copy (bit 24): then
+    // consecutive tiles read neighbouring source rows instead of rows TW apart
+    int tw_i, th_i, chunk;
+    if (p.flags & (1 << 24)) {
+        th_i = t % p.nTh;
+        const int t2 = t / p.nTh;
+        tw_i = t2 % p.nTw;
+        chunk = t2 / p.nTw;
+    } else {
+        tw_i = t % p.nTw;
+        const int t2 = t / p.nTw;
+        th_i = t2 % p.nTh;
+        chunk = t2 / p.nTh;
+    }
     const int h0 = th_i * TH, w0 = tw_i * TW;
     const int d_begin = chunk * p.dch;
     const int d_end = min(d_begin + p.dch, p.oD);
@@ -471,10 +481,20 @@ __global__ __launch_bounds__(NT) VT_ZPAIR_OCC void affine_march_zpair(const floa
 
     const int tid = threadIdx.x;
     const int t = xcd_contiguous(blockIdx.x, gridDim.x);
-    const int tw_i = t % p.nTw;
-    const int t2 = t / p.nTw;
-    const int th_i = t2 % p.nTh;
-    const int chunk = t2 / p.nTh;
+    // tile order inside a chunk: w fastest, or h fastest when the source is the in-plane transposed copy (bit 24): then
+    // consecutive tiles read neighbouring source rows instead of rows TW apart
+    int tw_i, th_i, chunk;
+    if (p.flags & (1 << 24)) {
+        th_i = t % p.nTh;
+        const int t2 = t / p.nTh;
+        tw_i = t2 % p.nTw;
+        chunk = t2 / p.nTw;
+    } else {
+        tw_i = t % p.nTw;
+        const int t2 = t / p.nTw;
+        th_i = t2 % p.nTh;
+        chunk = t2 / p.nTh;
+    }
     const int h0 = th_i * TH, w0 = tw_i * TW;
     const int d_begin = chunk * p.dch;
     const int d_end = min(d_begin + p.dch, p.oD);
