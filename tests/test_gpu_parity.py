@@ -341,7 +341,7 @@ def test_affine_batch_matches_single_calls(interp):
         sv.close()
 
 
-@pytest.mark.parametrize('interp', ['linear', 'filt_bspline'])
+@pytest.mark.parametrize('interp', ['linear', 'bspline', 'filt_bspline'])
 def test_oneshot_matches_resident_path(interp):
     """transform() on a host volume (vt_affine_oneshot: upload, prefilter, transform, download) against the resident
     StaticVolume path, which the other tests pin to the oracle; volume above the pinning threshold, results from the pool."""
@@ -354,7 +354,8 @@ def test_oneshot_matches_resident_path(interp):
              np.eye(4, dtype=np.float32),
              vt.utils.transform_matrix(rotation=(0, 100, 0), scale=(1.0, 1.2, 0.8), center=centre(shape)),
              vt.utils.transform_matrix(rotation=(25, -40, 70), rotation_order='sxyz', center=centre(shape)),
-             vt.utils.translation_matrix((300.0, 0, 0))]
+             vt.utils.translation_matrix((300.0, 0, 0)),
+             vt.utils.translation_matrix((20.5, 0, 0)), vt.utils.translation_matrix((-40.0, 3, 0))]
     for i, m in enumerate(cases):
         want = sv.affine(m)
         got = vt.affine(vol, m, interpolation=interp, device='gpu')
