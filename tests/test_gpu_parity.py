@@ -369,6 +369,39 @@ def test_oneshot_matches_resident_path(interp):
     sv.close()
 
 
+@pytest.mark.parametrize('interp', ['linear', 'bspline', 'filt_bspline'])
+def test_output_shape_other_than_source_shape(interp):
+    """vt_volume_set_output_shape (scipy's output_shape, transforms.py:136-150): every kernel family with an output grid
+    larger / smaller than the resident source, against the oracle's generalised entry point."""
+    import ctypes
+    lib = _native.load()
+    shape = (40, 44, 48)
+    vol = rand_vol(shape, 13)
+    src = oracle.prefilter(vol) if interp.startswith('filt') else vol
+    okind = 'bspline' if interp.startswith('filt') else interp
+    for out_shape in ((50, 60, 72), (33, 30, 40)):
+        h = ctypes.c_void_p()
+        _native.check(lib.vt_volume_create(0, *shape, _native.INTERP_CODES[interp], vol.ctypes.data, 0, ctypes.byref(h)), 'create')
+        _native.check(lib.vt_volume_set_output_shape(h, *out_shape), 'set_output_shape')
+        c = centre(shape)
+        for mname, m in (('axis0', vt.utils.transform_matrix(rotation=(0, 33, 0), translation=(1.5, -2, 3), center=c)),
+                         ('axis0_100', vt.utils.transform_matrix(rotation=(0, 100, 0), center=c)),
+                         ('axis1', vt.utils.transform_matrix(rotation=(0, 33, 0), rotation_order='sxyz', center=c)),
+                         ('axis2', vt.utils.transform_matrix(rotation=(0, 0, 33), rotation_order='sxyz', center=c)),
+                         ('general', vt.utils.transform_matrix(rotation=(25, -40, 70), rotation_order='sxyz', scale=(1.2, 0.9, 1.1), center=c))):
+            m32 = np.ascontiguousarray(m, dtype=np.float32)
+            want = oracle.affine_ex(src, np.asarray(m32, np.float64), okind, out_shape)
+            for flags in (0, _native.FORCE_TILED | _native.FORCE_XSWAP, _native.FORCE_TILED | _native.NO_ZPAIR, _native.FORCE_TILED | _native.NO_ZSEP,
+                          _native.FORCE_TILED | _native.NO_ZSEP | _native.FORCE_PACKED, _native.FORCE_DIRECT):
+                got = np.empty(out_shape, np.float32)
+                _native.check(lib.vt_volume_affine(h, m32.ctypes.data, got.ctypes.data, flags), 'affine')
+                assert np.abs(got - want).max() <= TOL[interp], (interp, out_shape, mname, flags)
+            pr = np.empty(out_shape[1:], np.float32)
+            _native.check(lib.vt_volume_project(h, m32.ctypes.data, pr.ctypes.data, 0), 'project')
+            assert np.abs(pr - want.astype(np.float64).sum(axis=0)).max() <= TOL[interp] * out_shape[0], (interp, out_shape, mname, 'projection')
+        lib.vt_volume_destroy(h)
+
+
 @pytest.mark.parametrize('interp', ['linear', 'bspline'])
 def test_projection_repeated_calls_large_plane(interp):
     """A plane large enough for the tiled kernels; successive projections must not see stale helper state."""
