@@ -370,8 +370,13 @@ __global__ __launch_bounds__(NT) void affine_march_zsep(const float* __restrict_
             // Iteration j issues [loads(j+la), stores(j)], so after loads(g) this wave has issued stores(max(0,g-la) .. g-1)
             // and loads(g+1 .. min(g+la-1, ngroups-1)): wait until only those are outstanding.
             if (FAST && !no_stores && !no_loads) {
-                const int n = min(g, la) * nstore + min(la - 1, ngroups - 1 - g) * nload;
-                wait_vmcnt_le(n);
+                if (la == 1) {                    // the default depth: two cases, immediates (no jump table in the hot loop)
+                    if (g > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(nstore) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                } else {
+                    const int n = min(g, la) * nstore + min(la - 1, ngroups - 1 - g) * nload;
+                    wait_vmcnt_le(n);
+                }
             } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();         // everyone's loads landed; everyone is done with the slots reused next
             if (g + la < ngroups) {
@@ -688,10 +693,16 @@ __global__ __launch_bounds__(NT) VT_ZPAIR_OCC void affine_march_zpair(const floa
         // Iteration j issues [loads(j + la), stores(j)]: after this pair's loads the wave has issued the stores of the last
         // `la` iterations and the loads of the next la-1 pairs; wait until only those are outstanding.
         if (exact_stores) {
-            const int i = Pp - Pp0;
-            int n = st_hist[0] + (la > 1 ? st_hist[1] : 0) + (la > 2 ? st_hist[2] : 0);
-            n += min(la - 1, npairs - 1 - i) * nload_w;
-            wait_vmcnt_le(n);
+            if (la == 1) {                        // the default depth: three cases, immediates (no jump table in the hot loop)
+                if (st_hist[0] == 2 * NPIX) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPIX) : "memory");
+                else if (st_hist[0] == NPIX) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIX) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                const int i = Pp - Pp0;
+                int n = st_hist[0] + (la > 1 ? st_hist[1] : 0) + (la > 2 ? st_hist[2] : 0);
+                n += min(la - 1, npairs - 1 - i) * nload_w;
+                wait_vmcnt_le(n);
+            }
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
