@@ -658,14 +658,32 @@ __global__ __launch_bounds__(NT) VT_ZPAIR_OCC void affine_march_zpair(const floa
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(src2) + (int64_t)Pp_base * pair_bytes), 0, 0x7fffffff, 0x00020000);
 
+    // Specialised on NIT = staging vectors per thread (0 = run-time count with per-vector predicates) and FAST = every
+    // output voxel inside the source and the tile fully inside the output: the steady-state loop of the common case then
+    // carries no per-vector or per-pixel predicates (they cost scalar exec-mask work every pair).
+    auto run = [&](auto nit_c, auto fast_c) {
+    constexpr int NIT = decltype(nit_c)::value;
+    constexpr bool FAST = decltype(fast_c)::value;
+    constexpr int NLOOP = NIT > 0 ? NIT : kMaxIt;
+    const bool last_lane = tid + NT * (NLOOP - 1) < nvec;
+    const bool last_wave = wave_first + NT * (NLOOP - 1) < nvec;   // wave-uniform
     auto issue_pair = [&](int Pp, int slot) {
         const bool pair_ok = (unsigned)Pp < (unsigned)npairs_res;
         const int soff = pair_ok ? (Pp - Pp_base) * pair_bytes : 0;
         float* dst = lds + slot * slot_floats + 4 * wave_first;
 #pragma unroll
-        for (int it = 0; it < kMaxIt; ++it) {
-            if (wave_first + NT * it < nvec) {               // wave-uniform
-                const int off = pair_ok ? voff[it] : p.zero_off2;
+        for (int it = 0; it < NLOOP; ++it) {
+            const int off = pair_ok ? voff[it] : p.zero_off2;
+            if (NIT > 0 && it + 1 < NIT) {                   // full iterations: every lane stages a vector
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + (4 * NT) * it),
+                                                         16, off, soff, 0, 0);
+            } else if (NIT > 0) {
+                if (last_wave) {
+                    if (last_lane)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + (4 * NT) * it),
+                                                                 16, off, soff, 0, 0);
+                }
+            } else if (wave_first + NT * it < nvec) {        // wave-uniform
                 if (tid + NT * it < nvec)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + (4 * NT) * it),
                                                              16, off, soff, 0, 0);
@@ -674,8 +692,12 @@ __global__ __launch_bounds__(NT) VT_ZPAIR_OCC void affine_march_zpair(const floa
     };
 
     int nload_w = 0;                              // staging instructions this wave issues per pair (wave-uniform)
+    if (NIT > 0) {
+        nload_w = NIT - 1 + (last_wave ? 1 : 0);
+    } else {
 #pragma unroll
-    for (int it = 0; it < kMaxIt; ++it) nload_w += (wave_first + NT * it < nvec) ? 1 : 0;
+        for (int it = 0; it < kMaxIt; ++it) nload_w += (wave_first + NT * it < nvec) ? 1 : 0;
+    }
     const int npairs = PpN - Pp0 + 1;
     int Pp_next = Pp0, slot_next = 0;
     for (int a = 0; a < la && Pp_next <= PpN; ++a) {
@@ -692,7 +714,7 @@ __global__ __launch_bounds__(NT) VT_ZPAIR_OCC void affine_march_zpair(const floa
     for (int Pp = Pp0; Pp <= PpN; ++Pp) {
         // Iteration j issues [loads(j + la), stores(j)]: after this pair's loads the wave has issued the stores of the last
         // `la` iterations and the loads of the next la-1 pairs; wait until only those are outstanding.
-        if (exact_stores) {
+        if (FAST || exact_stores) {
             if (la == 1) {                        // the default depth: three cases, immediates (no jump table in the hot loop)
                 if (st_hist[0] == 2 * NPIX) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPIX) : "memory");
                 else if (st_hist[0] == NPIX) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIX) : "memory");
@@ -760,7 +782,7 @@ __global__ __launch_bounds__(NT) VT_ZPAIR_OCC void affine_march_zpair(const floa
             const int d = plane - 2 - p.zoff;
             const bool d_ok = (d >= d_begin) && (d < d_end);          // wave-uniform
             bool z_ok = true;
-            if (!all_valid) {
+            if (!FAST && !all_valid) {
                 const double ez = (double)d + p.m[3];
                 z_ok = (ez >= p.vlo[0]) && (ez < p.vhi[0]);
             }
@@ -776,7 +798,11 @@ __global__ __launch_bounds__(NT) VT_ZPAIR_OCC void affine_march_zpair(const floa
             }
             if (d_ok) {
                 const int64_t dofs = (int64_t)d * ostride;
-                if (exact_stores) {
+                if (FAST) {
+#pragma unroll
+                    for (int px = 0; px < NPIX; ++px) out[ooff[px] + dofs] = val[px];
+                    stores_prev += NPIX;
+                } else if (exact_stores) {
 #pragma unroll
                     for (int px = 0; px < NPIX; ++px) out[ooff[px] + dofs] = (in_yx[px] && z_ok) ? val[px] : 0.0f;
                     stores_prev += NPIX;
@@ -793,6 +819,18 @@ __global__ __launch_bounds__(NT) VT_ZPAIR_OCC void affine_march_zpair(const floa
         }
         st_hist[2] = st_hist[1]; st_hist[1] = st_hist[0]; st_hist[0] = stores_prev;
         slot_cur = (slot_cur + 1 == R) ? 0 : slot_cur + 1;
+    }
+    };
+    using std::integral_constant;
+    if (all_valid && exact_stores) {
+        switch ((nvec + NT - 1) / NT) {
+            case 1: run(integral_constant<int, 1>{}, integral_constant<bool, true>{}); break;
+            case 2: run(integral_constant<int, 2>{}, integral_constant<bool, true>{}); break;
+            case 3: run(integral_constant<int, 3>{}, integral_constant<bool, true>{}); break;
+            default: run(integral_constant<int, 4>{}, integral_constant<bool, true>{}); break;
+        }
+    } else {
+        run(integral_constant<int, 0>{}, integral_constant<bool, false>{});
     }
 }
 
