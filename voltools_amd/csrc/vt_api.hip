@@ -152,7 +152,69 @@ int init_device(int dev)
     return 0;
 }
 
+// Experiment overrides, read from the environment once per handle (vt_volume_create) -- never on the per-call path.
+// None is needed in production; tools/*.sh and the staging-mode parity test use them to reach planner alternatives.
+struct Tuning {
+    int tile = -1;                 // VT_TILE: force tile configuration (index into the kernel family's table)
+    int la = 0;                    // VT_LA: planes / pairs staged ahead by the marching kernels
+    int march_box = -1;            // VT_MARCH_BOX: 1 = bounding-box staging, 0 = packed row spans, -1 = planner's choice
+    int lxpad = -1;                // VT_LXPAD: LDS row padding of the pair kernel's boxes
+    int dch = 0;                   // VT_DCH: output planes per marching chunk
+    bool plain_tile_order = false; // VT_TILE_ORDER=0: packed kernel walks tiles in plain instead of blocked order
+    bool rswap_wfast = false;      // VT_RSWAP_WFAST: keep the w-fastest tile order on the in-plane transposed copy
+    bool exp_nostore = false;      // VT_EXP_NOSTORE / VT_EXP_NOLOAD: ablation builds (-DVT_EXPERIMENTS) only
+    bool exp_noload = false;
+    void read()
+    {
+        auto num = [](const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; };
+        tile = num("VT_TILE", -1);
+        la = num("VT_LA", 0);
+        march_box = num("VT_MARCH_BOX", -1);
+        if (march_box > 1) march_box = 1;
+        lxpad = num("VT_LXPAD", -1);
+        dch = std::max(0, num("VT_DCH", 0));
+        plain_tile_order = num("VT_TILE_ORDER", 1) == 0;
+        rswap_wfast = std::getenv("VT_RSWAP_WFAST") != nullptr;
+        exp_nostore = std::getenv("VT_EXP_NOSTORE") != nullptr;
+        exp_noload = std::getenv("VT_EXP_NOLOAD") != nullptr;
+    }
+};
+
 bool is_cubic(int interp) { return interp != VT_LINEAR; }
+
+// Chunk count of a marching launch.  Its workgroups all do the same work, so the chip runs them in rounds of `resident`
+// workgroups and a launch of 5.33 rounds takes almost as long as one of 6 ([measured] 512^3 cubic at 0 / 30 degrees:
+// 8 chunks = 5.33 rounds 0.274 / 0.304 ms; 6 chunks = 4.0 rounds 0.261 / 0.296; 3 chunks = 2.0 rounds 0.249 / 0.297;
+// 4 chunks = 2.67 rounds 0.260 / 0.314; tools/dch_rounds.sh).  Among chunk counts from n0/4 to 2*n0 take the one with the
+// least rounds x planes marched per chunk, a partial round charged at its fraction + 0.3; launches of many rounds (>= 16)
+// or of less than one keep n0, and so do planes with more tiles than the chip keeps resident (there deeper chunks
+// separate in-plane neighbours in time and their shared rows miss L2: 640^3 cubic 0.544 vs 0.498 ms).  Used by the pair
+// kernel only ([measured] 256^3 -9..-12 %, 384^3 -6..-10 %, 512^3 -2..-8 %).  `extra` = source planes a chunk stages beyond
+// its output planes.
+int64_t round_aware_chunks(int64_t oD, int g, int64_t inplane, int64_t resident, int64_t n0, int extra, int min_dch, int64_t n_floor)
+{
+    if (resident <= 0 || inplane > resident || inplane * n0 >= 16 * resident) return n0;
+    auto cost = [&](int64_t n) {
+        int64_t dch = (oD + n - 1) / n;
+        dch = (dch + g - 1) / g * g;
+        const int64_t n_act = (oD + dch - 1) / dch;
+        const double R = (double)(inplane * n_act) / (double)resident;
+        if (R < 1.0) return 1e300;
+        const double fl = std::floor(R), fr = R - fl;
+        return (fl + (fr > 1e-9 ? std::min(1.0, fr + 0.3) : 0.0)) * (double)(dch + extra);
+    };
+    int64_t best = n0;
+    double best_c = cost(n0);
+    if (best_c >= 1e300) return n0;
+    best_c *= 0.97;                                   // switch only for a predicted gain of 3 % or more
+    const int64_t lo = std::max<int64_t>(std::max<int64_t>(1, n_floor), n0 / 4);
+    const int64_t hi = std::min<int64_t>(2 * n0, std::max<int64_t>(1, oD / std::max(1, min_dch)));
+    for (int64_t n = hi; n >= lo; --n) {
+        const double c = cost(n);
+        if (c < best_c) { best_c = c; best = n; }
+    }
+    return best;
+}
 bool is_filtered(int interp) { return interp == VT_FILT_BSPLINE || interp == VT_FILT_BSPLINE_SIMPLE; }
 
 }  // namespace
@@ -197,8 +259,7 @@ struct vt_volume {
     int cu_count = 256;
     // last launch, for vt_volume_info
     int last_kernel = 0, last_tile[3] = {0, 0, 0}, last_lds[3] = {0, 0, 0}, last_lds_bytes = 0, last_grid = 0;
-    int force_cfg = -1;                // VT_TILE environment override (experiments)
-    int force_la = 0;                  // VT_LA: groups staged ahead by the marching kernel (experiments)
+    Tuning tune;                       // experiment overrides (environment, read at create)
 };
 
 namespace {
@@ -350,10 +411,10 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
         if (cubic && !(flags & VT_NO_ZPAIR) && (int64_t)v->H * (2 * (((v->W + 3) & ~3) + 4)) * 4 < 0x7fffffffLL) {
             const double fl = std::floor(m[3]);
             for (int c = 0; c < zpair_config_count() && plan->kind != 5; ++c) {
-                if (v->force_cfg >= 0 && c != v->force_cfg) continue;
+                if (v->tune.tile >= 0 && c != v->tune.tile) continue;
                 int th, tw, la, nt;
                 zpair_config(c, &th, &tw, &la, &nt);
-                if (v->force_la > 0) la = std::min(3, v->force_la);
+                if (v->tune.la > 0) la = std::min(3, v->tune.la);
                 const int vec_max = nt * march_max_it();
                 const int T[3] = {1, th, tw};
                 int L[3] = {0, 0, 0};
@@ -369,7 +430,7 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
                 // boxes (stride padding fetched from the zero vector) vs packed spans [measured]: 512^3 sweep mean 0.292 vs
                 // 0.312 ms, 1024^3 2.25-2.33 vs 2.28-2.38 ms -> boxes; VT_MARCH_BOX=0 selects packed spans
                 bool zp_box = true;
-                if (const char* e = std::getenv("VT_MARCH_BOX")) zp_box = std::atoi(e) != 0;
+                if (v->tune.march_box >= 0) zp_box = v->tune.march_box != 0;
                 const int lx_used = L[2];                         // columns that hold data; the rest is stride padding
                 int best_lx = L[2];
                 double best_f = 1e300;
@@ -380,7 +441,7 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
                     const double f = gather_conflict_factor(m[6], m[10], L[2] + pad, 1) * (1.0 + 0.015 * pad);
                     if (f < best_f - 1e-9) { best_f = f; best_lx = L[2] + pad; }
                 }
-                if (const char* e = std::getenv("VT_LXPAD")) best_lx = L[2] + std::atoi(e);
+                if (v->tune.lxpad >= 0) best_lx = L[2] + v->tune.lxpad;
                 L[2] = best_lx;
                 int slot_floats = L[1] * L[2] * 2;
                 if (!zp_box) {
@@ -417,14 +478,18 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
                 p->zero_off2 = 2 * ((v->W + 3) & ~3) * 4;
                 const int64_t inplane = (int64_t)p->nTh * p->nTw;
                 int target_dch = ((int64_t)v->H * v->W <= 512 * 512) ? 64 : 32;
-                if (const char* e = std::getenv("VT_DCH")) target_dch = std::max(2, std::atoi(e));
+                if (v->tune.dch > 0) target_dch = std::max(2, v->tune.dch);
                 int64_t nchunks = std::max<int64_t>(1, (v->oD + target_dch - 1) / target_dch);
                 // small volumes: shorter chunks until the launch has ~4 workgroups per CU (a 128^3 volume has only 32
                 // in-plane tiles: 64-plane chunks would leave 3/4 of the chip idle), but not below 8 planes per chunk
-                if (!std::getenv("VT_DCH"))
+                if (v->tune.dch <= 0)
                     nchunks = std::max(nchunks, std::min<int64_t>((4 * (int64_t)v->cu_count + inplane - 1) / inplane, (v->oD + 7) / 8));
                 const int64_t pair_bytes = (int64_t)v->H * p->sP2 * 4;
-                nchunks = std::max<int64_t>(nchunks, ((int64_t)(v->oD / 2 + 4) * pair_bytes) / 0x60000000LL + 1);
+                const int64_t n_addr = ((int64_t)(v->oD / 2 + 4) * pair_bytes) / 0x60000000LL + 1;   // 31-bit scalar offsets
+                nchunks = std::max<int64_t>(nchunks, n_addr);
+                if (v->tune.dch <= 0)
+                    nchunks = round_aware_chunks(v->oD, 2, inplane, (int64_t)v->cu_count * march_blocks_per_cu(true, plan->cfg, v->interp, plan->lds_bytes),
+                                                 nchunks, 4, 8, n_addr);
                 int dch = (int)((v->oD + nchunks - 1) / nchunks);
                 dch = (dch + 1) & ~1;
                 nchunks = (v->oD + dch - 1) / dch;
@@ -440,12 +505,12 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
         // of the packed image make worse (measured 0.48 vs 0.39 ms at 45 degrees), so they stage the bounding box with
         // a conflict-aware row stride.  VT_MARCH_BOX=0/1 overrides.
         bool march_box = cubic;
-        if (const char* e = std::getenv("VT_MARCH_BOX")) march_box = std::atoi(e) != 0;
+        if (v->tune.march_box >= 0) march_box = v->tune.march_box != 0;
         for (int c = 0; c < march_config_count(); ++c) {
-            if (v->force_cfg >= 0 && c != v->force_cfg) continue;
+            if (v->tune.tile >= 0 && c != v->tune.tile) continue;
             int th, tw, g, la, nt;
             march_config(c, &th, &tw, &g, &la, &nt);
-            if (v->force_la > 0) la = v->force_la;
+            if (v->tune.la > 0) la = v->tune.la;
             const int vec_max = nt * march_max_it();
             const int T[3] = {1, th, tw};
             int L[3] = {0, 0, 0};
@@ -495,7 +560,7 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
                 p->Lz = ring; p->Ly = std::min(L[1], march_rows_max()); p->Lx = L[2]; p->Lx_used = lx_used4 ? lx_used4 : L[2];
                 p->slot_floats = slot_floats;
                 p->flags = (flags & VT_KEEP_OUTSIDE) | (march_box ? (1 << 20) : 0) |
-                           (std::getenv("VT_EXP_NOSTORE") ? (1 << 21) : 0) | (std::getenv("VT_EXP_NOLOAD") ? (1 << 22) : 0);
+                           (v->tune.exp_nostore ? (1 << 21) : 0) | (v->tune.exp_noload ? (1 << 22) : 0);
                 break;                            // first fit wins (planning is on the per-call path: keep it cheap)
             }
         }
@@ -526,8 +591,11 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
             nchunks = std::max(nchunks, std::min<int64_t>((4 * (int64_t)v->cu_count + inplane - 1) / inplane, (v->oD + 3) / 4));
             // the chunk's planes are addressed with a 31-bit scalar byte offset from its first plane
             const int64_t plane_bytes = (int64_t)v->H * v->P * 4;
-            nchunks = std::max<int64_t>(nchunks, ((int64_t)v->oD * plane_bytes) / 0x60000000LL + 1);
-            if (const char* e = std::getenv("VT_DCH")) nchunks = std::max<int64_t>(1, (v->oD + std::atoi(e) - 1) / std::max(1, std::atoi(e)));
+            const int64_t n_addr = ((int64_t)v->oD * plane_bytes) / 0x60000000LL + 1;
+            nchunks = std::max<int64_t>(nchunks, n_addr);
+            // (no round-aware chunk count here: [measured] the linear kernel loses more L2 sharing with deeper chunks than
+            // it gains from whole rounds -- 512^3 0.250 vs 0.220 ms, 640^3 0.442 vs 0.419)
+            if (v->tune.dch > 0) nchunks = std::max<int64_t>(1, (v->oD + v->tune.dch - 1) / v->tune.dch);
             int dch = (int)((v->oD + nchunks - 1) / nchunks);
             dch = ((dch + g - 1) / g) * g;
             nchunks = (v->oD + dch - 1) / dch;
@@ -540,7 +608,7 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
     }
     double best_cost = 1e300, box_bpv = 1e300;
     for (int c = 0; c < tile_config_count(); ++c) {
-        if (v->force_cfg >= 0 && c != v->force_cfg) continue;
+        if (v->tune.tile >= 0 && c != v->tune.tile) continue;
         int T[3];
         tile_config(c, &T[0], &T[1], &T[2]);
         int L[3];
@@ -587,7 +655,7 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
             AffineParams pp = *p;
             pk.kind = 0;
             for (int c = 0; c < packed_config_count(); ++c) {
-                if (v->force_cfg >= 0 && c != v->force_cfg) continue;
+                if (v->tune.tile >= 0 && c != v->tune.tile) continue;
                 int T[3];
                 packed_config(c, &T[0], &T[1], &T[2]);
                 // too few tiles to amortise the per-workgroup set-up (see `enough` below): do not even plan it -- the span
@@ -661,7 +729,7 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
                 const int64_t ntiles = (int64_t)p->nTd * p->nTh * p->nTw;
                 if (ntiles <= 0x7fffffffLL) {
                     // persistent workgroups: as many as stay resident, a multiple of 8 (one share per XCD)
-                    if (const char* e = std::getenv("VT_TILE_ORDER")) if (std::atoi(e) == 0) p->flags |= (1 << 23);
+                    if (v->tune.plain_tile_order) p->flags |= (1 << 23);
                     int64_t nwg = std::min<int64_t>(ntiles, (int64_t)v->cu_count * std::max(1, plan->blocks_per_cu));
                     nwg = std::max<int64_t>(8, (nwg + 7) / 8 * 8);
                     plan->grid = (int)nwg;
@@ -734,7 +802,7 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
         sw.D = v->H; sw.H = v->D; sw.W = v->W; sw.P = v->P;
         sw.oD = v->oH; sw.oH = v->oD; sw.oW = v->oW;
         sw.plane0 = 0; sw.gD = v->H; sw.out_plane0 = 0;
-        sw.lds_limit = v->lds_limit; sw.cu_count = v->cu_count; sw.force_cfg = v->force_cfg; sw.force_la = v->force_la;
+        sw.lds_limit = v->lds_limit; sw.cu_count = v->cu_count; sw.tune = v->tune;
         const int pi[3] = {1, 0, 2};
         double ms[12];
         for (int r = 0; r < 3; ++r) {
@@ -782,7 +850,7 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
         sw.D = v->W; sw.H = v->H; sw.W = v->D; sw.P = ((v->D + 3) & ~3) + 4;
         sw.oD = v->oW; sw.oH = v->oH; sw.oW = v->oD;
         sw.plane0 = 0; sw.gD = v->W; sw.out_plane0 = 0;
-        sw.lds_limit = v->lds_limit; sw.cu_count = v->cu_count; sw.force_cfg = v->force_cfg; sw.force_la = v->force_la;
+        sw.lds_limit = v->lds_limit; sw.cu_count = v->cu_count; sw.tune = v->tune;
         const int pi[3] = {2, 1, 0};
         double ms[12];
         for (int r = 0; r < 3; ++r) {
@@ -837,7 +905,7 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
         sw.D = v->D; sw.H = v->W; sw.W = v->H; sw.P = ((v->H + 3) & ~3) + 4;
         sw.oD = v->oD; sw.oH = v->oH; sw.oW = v->oW;
         sw.plane0 = v->plane0; sw.gD = v->gD; sw.out_plane0 = v->out_plane0;
-        sw.lds_limit = v->lds_limit; sw.cu_count = v->cu_count; sw.force_cfg = v->force_cfg; sw.force_la = v->force_la;
+        sw.lds_limit = v->lds_limit; sw.cu_count = v->cu_count; sw.tune = v->tune;
         double ms[12];
         for (int c = 0; c < 4; ++c) { ms[c] = m[c]; ms[4 + c] = m[8 + c]; ms[8 + c] = m[4 + c]; }
         AffineParams ps;
@@ -863,7 +931,7 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
             p = ps; plan = plans;
             src_plain = v->d_src_r; pair_slot = &v->d_src_r_zp;
             srcD = v->D; srcH = v->W; pair_W = v->H; pair_P = v->Pr;
-            if (!std::getenv("VT_RSWAP_WFAST")) p.flags |= (1 << 24);          // h-fastest tile order on the transposed copy
+            if (!v->tune.rswap_wfast) p.flags |= (1 << 24);          // h-fastest tile order on the transposed copy
         }
     }
     if (plan.kind == 0) {
@@ -961,8 +1029,7 @@ int create_common(int dev, int D, int H, int W, int interp, const float* data, i
     v->dev = dev; v->interp = interp; v->D = D; v->H = H; v->W = W;
     v->oD = oD; v->oH = H; v->oW = W;
     v->plane0 = plane0; v->gD = gD; v->out_plane0 = out_plane0;
-    if (const char* t = std::getenv("VT_TILE")) v->force_cfg = std::atoi(t);
-    if (const char* t = std::getenv("VT_LA")) v->force_la = std::atoi(t);
+    v->tune.read();
 
     auto cleanup = [&](int code) {
         vt_volume_destroy(v);

@@ -188,6 +188,7 @@ int march_config_count();
 void march_config(int idx, int* th, int* tw, int* g, int* la, int* nt);
 int zpair_config_count();
 void zpair_config(int idx, int* th, int* tw, int* la, int* nt);
+int march_blocks_per_cu(bool pair, int cfg, int interp, int lds_bytes);   // resident workgroups per CU (occupancy calculator, cached)
 hipError_t launch_affine_zpair(int cfg, int interp, const float* src2, float* out, const AffineParams& p,
                                int grid, int lds_bytes, hipStream_t stream);
 hipError_t launch_relayout_zpair(const float* src, float* dst, int D, int H, int W, int P, int P2, hipStream_t stream);

@@ -23,6 +23,8 @@
 // If a tile's packed footprint exceeds the slot size planned on the host (an estimate with margin), that workgroup falls
 // back to gathering its voxels straight from global memory -- slower, never wrong.
 #include "vt_internal.h"
+#include <mutex>
+#include <unordered_map>
 #include "vt_device.h"
 
 #include <climits>
@@ -979,6 +981,28 @@ hipError_t init_march_kernels()
             if (e != hipSuccess) return e;
         }
     return hipSuccess;
+}
+
+// Workgroups of this kernel that one CU keeps resident (register- and LDS-limited), from the runtime's occupancy
+// calculator; cached per (kernel, LDS size) -- the planner calls this on the per-call path.
+int march_blocks_per_cu(bool pair, int cfg, int interp, int lds_bytes)
+{
+    static std::mutex mu;
+    static std::unordered_map<uint64_t, int> cache;
+    const int kind = interp_kind(interp);
+    const uint64_t key = ((uint64_t)(pair ? 1 : 0) << 40) | ((uint64_t)cfg << 34) | ((uint64_t)kind << 32) | (uint32_t)lds_bytes;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    int n = 0;
+    const void* fn = pair ? reinterpret_cast<const void*>(zpair_entry(cfg, kind)) : reinterpret_cast<const void*>(march_entry(cfg, kind));
+    const int nt = pair ? kZpair[cfg].nt : kMarch[cfg].nt;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, nt, (size_t)lds_bytes) != hipSuccess || n < 1) {
+        (void)hipGetLastError();
+        n = 1;
+    }
+    cache.emplace(key, n);
+    return n;
 }
 
 hipError_t launch_affine_march(int cfg, int interp, const float* src, float* out, const AffineParams& p,
