@@ -160,6 +160,7 @@ struct Tuning {
     int march_box = -1;            // VT_MARCH_BOX: 1 = bounding-box staging, 0 = packed row spans, -1 = planner's choice
     int lxpad = -1;                // VT_LXPAD: LDS row padding of the pair kernel's boxes
     int dch = 0;                   // VT_DCH: output planes per marching chunk
+    int blk_h = -1, blk_w = -1;    // VT_BLK_H / VT_BLK_W: blocked tile order of the marching kernels (tiles per block; 0 = plain order)
     bool plain_tile_order = false; // VT_TILE_ORDER=0: packed kernel walks tiles in plain instead of blocked order
     bool rswap_wfast = false;      // VT_RSWAP_WFAST: keep the w-fastest tile order on the in-plane transposed copy
     bool exp_nostore = false;      // VT_EXP_NOSTORE / VT_EXP_NOLOAD: ablation builds (-DVT_EXPERIMENTS) only
@@ -173,6 +174,8 @@ struct Tuning {
         if (march_box > 1) march_box = 1;
         lxpad = num("VT_LXPAD", -1);
         dch = std::max(0, num("VT_DCH", 0));
+        blk_h = num("VT_BLK_H", -1);
+        blk_w = num("VT_BLK_W", -1);
         plain_tile_order = num("VT_TILE_ORDER", 1) == 0;
         rswap_wfast = std::getenv("VT_RSWAP_WFAST") != nullptr;
         exp_nostore = std::getenv("VT_EXP_NOSTORE") != nullptr;
@@ -452,6 +455,12 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
                     slot_floats = vecs * 4;
                     if (vecs > vec_max) continue;
                 } else if (L[1] * (L[2] / 2) > vec_max) continue;
+                // planes with more tiles than the chip keeps resident: one more pair in flight where three slots still
+                // leave three workgroups per CU ([measured] 1024^3: 2.020 -> 1.972 ms at 0 degrees, 2.221 -> 2.202 at 30;
+                // 512^3, whole layers resident: 0.258 -> 0.263, so not there)
+                if (v->tune.la <= 0 && la == 1 && 9LL * slot_floats * 4 <= 160 * 1024 &&
+                    (int64_t)((v->oH + th - 1) / th) * ((v->oW + tw - 1) / tw) > 3LL * v->cu_count)
+                    la = 2;
                 const int64_t bytes = std::max<int64_t>((int64_t)(la + 1) * slot_floats * 4, zp_box ? 0 : march_table_bytes());
                 if (bytes > v->lds_limit) continue;
                 plan->kind = 5; plan->cfg = c; plan->td = 2; plan->th = th; plan->tw = tw;
@@ -495,6 +504,7 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
                 nchunks = (v->oD + dch - 1) / dch;
                 p->dch = dch;
                 p->nTd = (int)nchunks;
+                if (v->tune.blk_h > 0 && v->tune.blk_w > 0) { p->blk_h = v->tune.blk_h; p->blk_w = v->tune.blk_w; }
                 const int64_t grid = inplane * nchunks;
                 if (grid <= 0x7fffffffLL) { plan->grid = (int)grid; return 0; }
                 plan->kind = 1;
@@ -601,6 +611,7 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
             nchunks = (v->oD + dch - 1) / dch;
             p->dch = dch;
             p->nTd = (int)nchunks;
+            if (v->tune.blk_h > 0 && v->tune.blk_w > 0) { p->blk_h = v->tune.blk_h; p->blk_w = v->tune.blk_w; }
             const int64_t grid = inplane * nchunks;
             if (grid <= 0x7fffffffLL) { plan->grid = (int)grid; return 0; }
             plan->kind = 1;

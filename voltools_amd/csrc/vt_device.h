@@ -56,6 +56,40 @@ __device__ __forceinline__ int xcd_contiguous(int b, int n)
 }
 
 
+// Tile order of the marching kernels inside one chunk layer of nTh x nTw in-plane tiles:
+//   * w fastest (default), or h fastest when the source is the in-plane transposed copy (flag bit 24): consecutive tiles
+//     then read neighbouring source rows instead of rows TW apart;
+//   * blocked (p.blk_h > 0): blocks of blk_h x blk_w tiles, w fastest inside a block, blocks running DOWN a block column
+//     first.  The workgroups resident on one XCD are consecutive tiles; when a layer has more tiles than the chip keeps
+//     resident, a few stacked blocks make their union a compact patch whose rotated footprints overlap inside the XCD's
+//     L2 instead of a 1024-wide strip of tiles whose boxes share little (1024^3 cubic at 30 degrees read 2.4x the
+//     algorithmic bytes from HBM with the strip order).  Partial blocks at the right / bottom edges are decoded exactly,
+//     so the grid has no padding ids.
+__device__ __forceinline__ void march_tile(const AffineParams& p, int t, int& th_i, int& tw_i, int& chunk)
+{
+    const int per_layer = p.nTh * p.nTw;
+    chunk = t / per_layer;
+    const int u = t - chunk * per_layer;
+    if (p.blk_h > 0) {
+        const int col_tiles = p.nTh * p.blk_w;            // tiles in a full block column
+        const int bc = u / col_tiles;
+        const int wc = min(p.blk_w, p.nTw - bc * p.blk_w);
+        const int u1 = u - bc * col_tiles;
+        const int blk_tiles = p.blk_h * wc;
+        const int br = u1 / blk_tiles;
+        const int u2 = u1 - br * blk_tiles;
+        const int r = u2 / wc;
+        th_i = br * p.blk_h + r;
+        tw_i = bc * p.blk_w + (u2 - r * wc);
+    } else if (p.flags & (1 << 24)) {
+        tw_i = u / p.nTh;
+        th_i = u - tw_i * p.nTh;
+    } else {
+        th_i = u / p.nTw;
+        tw_i = u - th_i * p.nTw;
+    }
+}
+
 // 3-D tiles in 4 x 4 x 4 super-blocks (w fastest inside a block and across blocks): consecutive tile ids -- the tiles
 // that are in flight together on one XCD -- form a compact region of the volume, so the footprints that neighbouring
 // tiles share (in all three directions) are fetched from HBM once and then hit the XCD's L2.  With the plain

@@ -41,6 +41,7 @@ struct AffineParams {
     int32_t ord[3];            // column order of the skirt test's fma chain (0,1,2; permuted when the launch runs on an axis-exchanged copy,
                                // so that the chain is the original problem's and boundary voxels classify as in affine_direct)
     int64_t ostride, orow;     // marching kernels: element stride between output planes / rows (oH*oW, oW unless axes are swapped)
+    int blk_h, blk_w;          // marching kernels: blocked tile order inside a chunk layer (tiles per block; 0 = plain order)
 };
 
 

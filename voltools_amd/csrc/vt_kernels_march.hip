@@ -144,20 +144,8 @@ __global__ __launch_bounds__(NT) void affine_march_zsep(const float* __restrict_
 
     const int tid = threadIdx.x;
     const int t = xcd_contiguous(blockIdx.x, gridDim.x);
-    // tile order inside a chunk: w fastest, or h fastest when the source is the in-plane transposed copy (bit 24): then
-    // consecutive tiles read neighbouring source rows instead of rows TW apart
     int tw_i, th_i, chunk;
-    if (p.flags & (1 << 24)) {
-        th_i = t % p.nTh;
-        const int t2 = t / p.nTh;
-        tw_i = t2 % p.nTw;
-        chunk = t2 / p.nTw;
-    } else {
-        tw_i = t % p.nTw;
-        const int t2 = t / p.nTw;
-        th_i = t2 % p.nTh;
-        chunk = t2 / p.nTh;
-    }
+    march_tile(p, t, th_i, tw_i, chunk);
     const int h0 = th_i * TH, w0 = tw_i * TW;
     const int d_begin = chunk * p.dch;
     const int d_end = min(d_begin + p.dch, p.oD);
@@ -488,20 +476,8 @@ __global__ __launch_bounds__(NT) VT_ZPAIR_OCC void affine_march_zpair(const floa
 
     const int tid = threadIdx.x;
     const int t = xcd_contiguous(blockIdx.x, gridDim.x);
-    // tile order inside a chunk: w fastest, or h fastest when the source is the in-plane transposed copy (bit 24): then
-    // consecutive tiles read neighbouring source rows instead of rows TW apart
     int tw_i, th_i, chunk;
-    if (p.flags & (1 << 24)) {
-        th_i = t % p.nTh;
-        const int t2 = t / p.nTh;
-        tw_i = t2 % p.nTw;
-        chunk = t2 / p.nTw;
-    } else {
-        tw_i = t % p.nTw;
-        const int t2 = t / p.nTw;
-        th_i = t2 % p.nTh;
-        chunk = t2 / p.nTh;
-    }
+    march_tile(p, t, th_i, tw_i, chunk);
     const int h0 = th_i * TH, w0 = tw_i * TW;
     const int d_begin = chunk * p.dch;
     const int d_end = min(d_begin + p.dch, p.oD);
@@ -721,6 +697,10 @@ __global__ __launch_bounds__(NT) VT_ZPAIR_OCC void affine_march_zpair(const floa
                 if (st_hist[0] == 2 * NPIX) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPIX) : "memory");
                 else if (st_hist[0] == NPIX) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIX) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else if (NIT > 0 && la == 2 && st_hist[0] == 2 * NPIX && st_hist[1] == 2 * NPIX && Pp < PpN) {
+                // steady state of depth 2: the stores of two iterations and one pair of loads stay in flight
+                if (last_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NPIX + NLOOP) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NPIX + NLOOP - 1) : "memory");
             } else {
                 const int i = Pp - Pp0;
                 int n = st_hist[0] + (la > 1 ? st_hist[1] : 0) + (la > 2 ? st_hist[2] : 0);
