@@ -163,8 +163,9 @@ struct Tuning {
     int blk_h = -1, blk_w = -1;    // VT_BLK_H / VT_BLK_W: blocked tile order of the marching kernels (tiles per block; 0 = plain order)
     bool plain_tile_order = false; // VT_TILE_ORDER=0: packed kernel walks tiles in plain instead of blocked order
     bool rswap_wfast = false;      // VT_RSWAP_WFAST: keep the w-fastest tile order on the in-plane transposed copy
-    bool exp_nostore = false;      // VT_EXP_NOSTORE / VT_EXP_NOLOAD: ablation builds (-DVT_EXPERIMENTS) only
+    bool exp_nostore = false;      // VT_EXP_NOSTORE / VT_EXP_NOLOAD / VT_EXP_NOLDS: ablation builds (-DVT_EXPERIMENTS) only
     bool exp_noload = false;
+    bool exp_nolds = false;
     void read()
     {
         auto num = [](const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; };
@@ -180,6 +181,7 @@ struct Tuning {
         rswap_wfast = std::getenv("VT_RSWAP_WFAST") != nullptr;
         exp_nostore = std::getenv("VT_EXP_NOSTORE") != nullptr;
         exp_noload = std::getenv("VT_EXP_NOLOAD") != nullptr;
+        exp_nolds = std::getenv("VT_EXP_NOLDS") != nullptr;
     }
 };
 
@@ -467,7 +469,8 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
                 plan->lds_bytes = (int)bytes;
                 p->Lz = la + 1; p->Ly = L[1]; p->Lx = L[2]; p->Lx_used = lx_used;
                 p->slot_floats = slot_floats;
-                p->flags = (flags & VT_KEEP_OUTSIDE) | (zp_box ? (1 << 20) : 0);
+                p->flags = (flags & VT_KEEP_OUTSIDE) | (zp_box ? (1 << 20) : 0) | (v->tune.exp_nostore ? (1 << 21) : 0) |
+                           (v->tune.exp_noload ? (1 << 22) : 0) | (v->tune.exp_nolds ? (1 << 26) : 0);
             }
             if (plan->kind == 5) {
                 const int T[3] = {1, plan->th, plan->tw};

@@ -639,6 +639,11 @@ __global__ __launch_bounds__(NT) VT_ZPAIR_OCC void affine_march_zpair(const floa
     // Specialised on NIT = staging vectors per thread (0 = run-time count with per-vector predicates) and FAST = every
     // output voxel inside the source and the tile fully inside the output: the steady-state loop of the common case then
     // carries no per-vector or per-pixel predicates (they cost scalar exec-mask work every pair).
+#ifdef VT_EXPERIMENTS      // make EXTRA=-DVT_EXPERIMENTS: VT_EXP_NOSTORE / VT_EXP_NOLOAD / VT_EXP_NOLDS ablations
+    const bool no_stores = (p.flags & (1 << 21)) != 0, no_loads = (p.flags & (1 << 22)) != 0, no_lds = (p.flags & (1 << 26)) != 0;
+#else
+    constexpr bool no_stores = false, no_loads = false, no_lds = false;
+#endif
     auto run = [&](auto nit_c, auto fast_c) {
     constexpr int NIT = decltype(nit_c)::value;
     constexpr bool FAST = decltype(fast_c)::value;
@@ -646,6 +651,7 @@ __global__ __launch_bounds__(NT) VT_ZPAIR_OCC void affine_march_zpair(const floa
     const bool last_lane = tid + NT * (NLOOP - 1) < nvec;
     const bool last_wave = wave_first + NT * (NLOOP - 1) < nvec;   // wave-uniform
     auto issue_pair = [&](int Pp, int slot) {
+        if (no_loads) return;
         const bool pair_ok = (unsigned)Pp < (unsigned)npairs_res;
         const int soff = pair_ok ? (Pp - Pp_base) * pair_bytes : 0;
         float* dst = lds + slot * slot_floats + 4 * wave_first;
@@ -683,7 +689,9 @@ __global__ __launch_bounds__(NT) VT_ZPAIR_OCC void affine_march_zpair(const floa
         ++Pp_next;
         slot_next = (slot_next + 1 == R) ? 0 : slot_next + 1;
     }
-    float c0[NPIX], c1[NPIX], c2[NPIX];           // in-plane partials of the three previous source planes
+    // in-plane partials of the three previous source planes.  (Tried: the z sums of a pair's two outputs as five packed FMAs
+    // instead of eight scalar ones, same summation order -- no measurable difference, the loop is not VALU-bound.)
+    float c0[NPIX], c1[NPIX], c2[NPIX];
 #pragma unroll
     for (int px = 0; px < NPIX; ++px) { c0[px] = 0.f; c1[px] = 0.f; c2[px] = 0.f; }
     int slot_cur = 0;
@@ -722,6 +730,12 @@ __global__ __launch_bounds__(NT) VT_ZPAIR_OCC void affine_march_zpair(const floa
         v2f part[NPIX];
         const unsigned pl_addr = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)pl;
         v2f tap[NPIX][16];
+        if (no_lds) {
+#pragma unroll
+            for (int px = 0; px < NPIX; ++px)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) asm volatile("" : "=v"(tap[px][k]));
+        } else
 #pragma unroll
         for (int px = 0; px < NPIX; ++px) {
 #pragma unroll
@@ -780,7 +794,10 @@ __global__ __launch_bounds__(NT) VT_ZPAIR_OCC void affine_march_zpair(const floa
             }
             if (d_ok) {
                 const int64_t dofs = (int64_t)d * ostride;
-                if (FAST) {
+                if (FAST && no_stores) {
+#pragma unroll
+                    for (int px = 0; px < NPIX; ++px) asm volatile("" ::"v"(val[px]));
+                } else if (FAST) {
 #pragma unroll
                     for (int px = 0; px < NPIX; ++px) out[ooff[px] + dofs] = val[px];
                     stores_prev += NPIX;
