@@ -111,6 +111,30 @@ def test_marching_staging_modes(interp, box, monkeypatch):
             assert np.abs(got - want).max() <= TOL[interp], (interp, box, mname, flags)
 
 
+@pytest.mark.parametrize('interp', ['linear', 'filt_bspline'])
+@pytest.mark.parametrize('knob', [{'VT_DCH': '8'}, {'VT_DCH': '64'}, {'VT_LA': '2'}, {'VT_LA': '3'}, {'VT_BLK_H': '3', 'VT_BLK_W': '2'},
+                                  {'VT_BLK_H': '2', 'VT_BLK_W': '5'}])
+def test_marching_schedule_does_not_change_results(interp, knob, monkeypatch):
+    """Chunk depth (incl. the round-aware default), ring depth and tile order are schedules: the marching kernels must return
+    the same bits for every one of them (each voxel is summed in one fixed order; the tile SIZE is not such a knob: pixel
+    coordinates are formed relative to the tile origin, a last-bit difference in the weights).  176 x 200 x 232: ragged tiles in
+    both in-plane directions, several chunks, partial blocks at both edges of the blocked order."""
+    shape = (176, 200, 232)
+    vol = rand_vol(shape, 7)
+    for mname in ('rot_inplane45', 'shift_frac'):
+        m = MATRICES[mname](shape)
+        ref, info = run_case(vol, m, interp)
+        assert info.last_kernel in (4, 5)
+        for k, val in knob.items():
+            monkeypatch.setenv(k, val)
+        got, info2 = run_case(vol, m, interp)
+        for k in knob:
+            monkeypatch.delenv(k)
+        assert info2.last_kernel in (4, 5)
+        assert np.array_equal(got, ref), (interp, knob, mname, float(np.abs(got - ref).max()))
+        assert np.abs(ref - oracle.affine(vol, m, interp)).max() <= TOL[interp]
+
+
 @pytest.mark.parametrize('interp', ['linear', 'bspline', 'filt_bspline'])
 def test_default_dispatch_uses_tiled_kernel_on_large_volumes(interp):
     shape = (96, 100, 104)
