@@ -105,6 +105,10 @@ int vt_memcpy_d2d(int dev, void* dst, const void* src, size_t bytes);
  * registered; the reference's `.get()`, transforms.py:223, lands in freshly allocated pageable memory). */
 int vt_host_register(int dev, void* ptr, size_t bytes);
 int vt_host_unregister(int dev, void* ptr);
+/* Release the device buffers the library keeps for recycling (resident sources and result staging of destroyed handles
+ * and one-shot calls, at most 16 GiB per device; cupy's memory pool plays this role for the reference:
+ * `cp.get_default_memory_pool().free_all_blocks()`). */
+int vt_device_trim(int dev);
 
 /* ---- StaticVolume: replaces volume.py:17-59 (upload, optional prefilter, texture build; done once) ----
  * `data` holds depth*height*width float32.  For filt_* interpolations the three-pass prefilter

@@ -372,7 +372,9 @@ def test_oneshot_matches_resident_path(interp):
     shape = (256, 192, 320)                       # 63 MB
     vol = rand_vol(shape, 21)
     sv = vt.StaticVolume(vol, interpolation=interp, device='gpu:0')
-    tol = 0.0                                     # same kernels on the same data
+    # the pipelined one-shot (axis-0-separable matrices) samples the plain resident layout slab by slab, the resident handle
+    # may pick the plane-pair / transposed copies: same arithmetic per tap, different summation order in the last bits
+    tol = TOL[interp]
     cases = [vt.utils.transform_matrix(rotation=(0, 33, 0), translation=(2.5, 1.0, -3.0), center=centre(shape)),
              vt.utils.translation_matrix((-7.25, 0.5, 0.0)),
              np.eye(4, dtype=np.float32),

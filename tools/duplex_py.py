@@ -6,7 +6,20 @@ import numpy as np
 if '--torch' in sys.argv:
     import torch  # noqa: F401
     torch.cuda.is_available()
-hip = ctypes.CDLL('libamdhip64.so')
+import os
+if '--vt' in sys.argv:      # let the package initialise first (its HIP runtime, its kernels, one transform), then run the raw sequence
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import importlib.util
+    import voltools_amd as vt
+    _v = np.random.RandomState(0).random_sample((64, 64, 64)).astype(np.float32)
+    vt.affine(_v, np.eye(4, dtype=np.float32), device='gpu')
+    if '--vtbig' in sys.argv:
+        _b = np.zeros((256, 256, 256), np.float32)
+        vt.affine(_b, np.eye(4, dtype=np.float32), device='gpu')
+    _spec = importlib.util.find_spec('torch')
+    hip = ctypes.CDLL(os.path.join(list(_spec.submodule_search_locations)[0], 'lib', 'libamdhip64.so'))
+else:
+    hip = ctypes.CDLL('libamdhip64.so')
 def ck(e, what=''):
     if e != 0:
         raise RuntimeError(f'HIP error {e} {what}')

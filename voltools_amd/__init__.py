@@ -9,7 +9,7 @@ __version__ = '0.1.0'
 from .transforms import AVAILABLE_INTERPOLATIONS, AVAILABLE_DEVICES, scale, shear, rotate, translate, transform, affine
 from .volume import StaticVolume
 from . import utils
-from ._native import DeviceArray
+from ._native import DeviceArray, free_cached_memory
 
 
 def empty(shape, device: str = 'gpu') -> DeviceArray:

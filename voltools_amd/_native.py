@@ -25,7 +25,7 @@ SRC_DEVICE, SLAB_LO_INTERIOR, SLAB_HI_INTERIOR = 1, 2, 4
 SYMBOLS = [
     'vt_device_count', 'vt_device_name', 'vt_device_props', 'vt_device_synchronize',
     'vt_malloc', 'vt_free', 'vt_memset_zero', 'vt_memcpy_h2d', 'vt_memcpy_d2h', 'vt_memcpy_d2d',
-    'vt_host_register', 'vt_host_unregister',
+    'vt_host_register', 'vt_host_unregister', 'vt_device_trim',
     'vt_volume_create', 'vt_volume_create_slab', 'vt_volume_destroy', 'vt_volume_info', 'vt_volume_stream',
     'vt_volume_sync', 'vt_volume_set_output_shape', 'vt_volume_affine', 'vt_volume_affine_f64',
     'vt_volume_project', 'vt_volume_project_f64', 'vt_volume_affine_batch',
@@ -92,6 +92,7 @@ def load():
     L.vt_memcpy_d2h.argtypes = [c_int, c_void_p, c_void_p, c_size_t]
     L.vt_host_register.argtypes = [c_int, c_void_p, c_size_t]
     L.vt_host_unregister.argtypes = [c_int, c_void_p]
+    L.vt_device_trim.argtypes = [c_int]
     L.vt_memcpy_d2d.argtypes = [c_int, c_void_p, c_void_p, c_size_t]
     L.vt_volume_create.argtypes = [c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, P(c_void_p)]
     L.vt_volume_create_slab.argtypes = [c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
@@ -131,6 +132,13 @@ def device_count() -> int:
     n = ctypes.c_int(0)
     check(load().vt_device_count(ctypes.byref(n)), 'vt_device_count')
     return n.value
+
+
+def free_cached_memory(dev: int = 0) -> None:
+    """Release the device buffers the library keeps for recycling (at most 16 GiB per device) and the pinned host result
+    buffers of the pool; the reference's users call ``cp.get_default_memory_pool().free_all_blocks()`` for the same purpose."""
+    check(load().vt_device_trim(dev), 'vt_device_trim')
+    _host_pool.clear(dev)
 
 
 def device_name(dev: int) -> str:

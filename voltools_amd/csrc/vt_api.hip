@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -63,9 +64,21 @@ struct DeviceCache {
     std::vector<hipEvent_t> events;
     std::vector<std::pair<size_t, void*>> bufs;
     size_t buf_bytes = 0;
+    std::vector<std::pair<size_t, void*>> big;     // large buffers, most recently released last
+    size_t big_bytes = 0;
+    // one-shot pipeline: two NON-blocking copy streams (uploads / downloads), one pipelined call at a time per device
+    std::mutex pipe_mu;
+    hipStream_t copy_up = nullptr, copy_dn = nullptr, pipe_k = nullptr;
 };
 DeviceCache g_cache[64];
 constexpr size_t kCacheBufMax = (size_t)64 << 20, kCacheTotalMax = (size_t)256 << 20;
+// Large buffers (resident sources, result staging) are recycled too, a few of them: a transfer to or from a device
+// allocation only reaches full PCIe duplex from its third pass on ([measured] tools/duplex_fresh.py: 512 MiB up + down
+// through a buffer from hipMalloc 19.4, 18.0, then 11.7 ms; a buffer allocated per call never gets there), so a one-shot
+// transform() that allocated its buffers per call could not overlap its upload with its download.  With 288 GB of HBM the
+// cache may hold 16 GiB; vt_device_trim releases it.
+constexpr size_t kBigBufMax = (size_t)8 << 30, kBigTotalMax = (size_t)16 << 30;
+constexpr size_t kBigCount = 6;
 
 hipError_t cached_stream(int dev, hipStream_t* s)
 {
@@ -114,11 +127,53 @@ hipError_t cached_malloc(int dev, void** p, size_t bytes)
                 return hipSuccess;
             }
     }
-    return hipMalloc(p, bytes);
+    if (dev < 64 && bytes > kCacheBufMax && bytes <= kBigBufMax) {
+        std::lock_guard<std::mutex> lk(g_cache[dev].mu);
+        auto& b = g_cache[dev].big;
+        for (size_t i = b.size(); i-- > 0;)
+            if (b[i].first == bytes) {
+                *p = b[i].second;
+                g_cache[dev].big_bytes -= bytes;
+                b.erase(b.begin() + (long)i);
+                return hipSuccess;
+            }
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess && dev < 64) {
+        // out of memory with buffers parked in the cache: release them and try once more
+        (void)hipGetLastError();
+        std::vector<std::pair<size_t, void*>> drop;
+        {
+            std::lock_guard<std::mutex> lk(g_cache[dev].mu);
+            drop.swap(g_cache[dev].big);
+            g_cache[dev].big_bytes = 0;
+        }
+        if (!drop.empty()) {
+            for (auto& d : drop) (void)hipFree(d.second);
+            e = hipMalloc(p, bytes);
+        }
+    }
+    return e;
 }
 void cached_free(int dev, void* p, size_t bytes)
 {
     if (!p) return;
+    if (dev < 64 && bytes > kCacheBufMax && bytes <= kBigBufMax) {
+        std::vector<void*> drop;
+        {
+            std::lock_guard<std::mutex> lk(g_cache[dev].mu);
+            auto& b = g_cache[dev].big;
+            b.emplace_back(bytes, p);
+            g_cache[dev].big_bytes += bytes;
+            while (!b.empty() && (b.size() > kBigCount || g_cache[dev].big_bytes > kBigTotalMax)) {   // oldest first
+                drop.push_back(b.front().second);
+                g_cache[dev].big_bytes -= b.front().first;
+                b.erase(b.begin());
+            }
+        }
+        for (void* d : drop) (void)hipFree(d);
+        return;
+    }
     if (dev < 64 && bytes <= kCacheBufMax) {
         std::lock_guard<std::mutex> lk(g_cache[dev].mu);
         if (g_cache[dev].bufs.size() < 16 && g_cache[dev].buf_bytes + bytes <= kCacheTotalMax) {
@@ -1118,6 +1173,142 @@ int create_common(int dev, int D, int H, int W, int interp, const float* data, i
     return 0;
 }
 
+// Pipelined one-shot.  The source is uploaded in chunks of planes into ONE resident buffer on a non-blocking
+// copy stream; the transform is launched per output slab on the handle's stream as soon as the last chunk that slab taps
+// has arrived (stream waits on the upload events); every finished slab is downloaded on a second non-blocking copy stream
+// while later chunks are still going up.  The sequence is the one of tools/probes/pipeline_probe.hip (512^3: 12.3 ms
+// against 19.8 ms sequential).  Requirements: an axis-0-separable matrix (each output plane taps a window of source
+// planes), an interpolation without prefilter (the z pass of the prefilter needs every plane), only the plain resident
+// layout (the secondary copies are built from a complete source).  Returns 1 when the call does not qualify.
+int oneshot_pipelined(int dev, const float* h_volume, int D, int H, int W, int interp, const float* m4x4, float* h_out, int flags)
+{
+    const size_t n = (size_t)D * H * W;
+    if (is_filtered(interp) || (flags & (VT_KEEP_OUTSIDE | VT_FORCE_DIRECT | VT_NO_ZSEP | VT_NO_MARCH)) || n * sizeof(float) < ((size_t)32 << 20) || D < 32)
+        return 1;
+    double m[16];
+    for (int i = 0; i < 16; ++i) m[i] = (double)m4x4[i];
+    if (!(m[0] == 1.0 && m[1] == 0.0 && m[2] == 0.0 && m[4] == 0.0 && m[8] == 0.0 && std::fabs(m[3]) < 1.0e9)) return 1;
+    for (int i = 0; i < 12; ++i)
+        if (!std::isfinite(m[i])) return 1;
+    if (dev >= 64) return 1;
+    std::unique_lock<std::mutex> pipe_lock(g_cache[dev].pipe_mu, std::try_to_lock);
+    if (!pipe_lock.owns_lock()) return 1;          // another thread is in the pipeline on this device: plain sequence
+    // Three streams created back to back: the runtime deals hardware queues to streams round-robin (4 queues), and a
+    // download that shares its hardware queue with the kernels is executed in that queue, in order, by a shader copy at half
+    // the PCIe rate ([measured] kernel j only started when download j-1 had finished, 27 GB/s) -- so the pipeline's kernels
+    // run on a stream of their own, created with the two copy streams, not on whichever stream the handle got.
+    hipStream_t& s_up = g_cache[dev].copy_up;
+    hipStream_t& s_dn = g_cache[dev].copy_dn;
+    hipStream_t& s_k = g_cache[dev].pipe_k;
+    if (!s_up || !s_dn || !s_k) {
+        if (hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&s_dn, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&s_k, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            s_up = s_dn = s_k = nullptr;         // (a leaked stream on this error path is harmless)
+            return 1;
+        }
+    }
+
+    static const bool trace = std::getenv("VT_PIPE_TRACE") != nullptr;
+    auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now_ms();
+    vt_volume_t* v = nullptr;
+    int rc = create_common(dev, D, H, W, interp, nullptr, kSrcNone, 0, D, 0, D, &v);
+    if (rc) return rc;
+    const double t_created = now_ms();
+    hipStream_t own_stream = v->stream;           // the slab launches go to the pipeline's kernel stream
+    v->stream = s_k;
+    float* d_out = nullptr;
+    int nch = D >= 256 ? 16 : 8;
+    if (const char* e = std::getenv("VT_PIPE_NCH")) nch = std::max(1, std::min(D / 2, std::atoi(e)));
+    const int Dc = (D + nch - 1) / nch;
+    std::vector<hipEvent_t> ev_up((size_t)nch, nullptr), ev_k((size_t)nch, nullptr), ev_dn((size_t)nch, nullptr);
+    auto finish = [&](int code) {
+        (void)hipStreamSynchronize(s_up);
+        (void)hipStreamSynchronize(s_k);
+        (void)hipStreamSynchronize(s_dn);
+        v->stream = own_stream;
+        for (hipEvent_t e : ev_up) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ev_k) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ev_dn) if (e) (void)hipEventDestroy(e);
+        cached_free(dev, d_out, n * sizeof(float));
+        vt_volume_destroy(v);
+        return code;
+    };
+#define VT_HIPP(call)                                                                                     \
+    do {                                                                                                  \
+        hipError_t e_ = (call);                                                                           \
+        if (e_ != hipSuccess) return finish(fail((int)e_, "%s: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__)); \
+    } while (0)
+    VT_HIPP(cached_malloc(dev, reinterpret_cast<void**>(&d_out), n * sizeof(float)));
+    // dependency-only events (no timestamps) unless the timeline is being traced
+    const unsigned evflags = trace ? hipEventDefault : hipEventDisableTiming;
+    for (int k = 0; k < nch; ++k) {
+        VT_HIPP(hipEventCreateWithFlags(&ev_up[(size_t)k], evflags)); VT_HIPP(hipEventCreateWithFlags(&ev_k[(size_t)k], evflags));
+        if (trace) VT_HIPP(hipEventCreateWithFlags(&ev_dn[(size_t)k], evflags));
+    }
+    PinnedScope pin_in(h_volume, n * sizeof(float)), pin_out(h_out, n * sizeof(float));
+    const double t_pinned = now_ms();
+
+    // uploads: all queued at once, in plane order (events complete in order)
+    for (int k = 0; k < nch; ++k) {
+        const int z0 = k * Dc, z1 = std::min(D, z0 + Dc);
+        if (z0 < z1)
+            VT_HIPP(hipMemcpy2DAsync(v->d_src + (size_t)z0 * H * v->P, (size_t)v->P * sizeof(float), h_volume + (size_t)z0 * H * W,
+                                     (size_t)W * sizeof(float), (size_t)W * sizeof(float), (size_t)(z1 - z0) * H, hipMemcpyHostToDevice, s_up));
+        VT_HIPP(hipEventRecord(ev_up[(size_t)k], s_up));
+    }
+    const double t_uploads = now_ms();
+    const int halo = is_cubic(interp) ? 2 : 1;
+    const int lflags = (flags | VT_OUT_DEVICE | VT_NO_ZPAIR | VT_NO_RSWAP) & ~VT_KEEP_OUTSIDE;
+    for (int j = 0; j < nch; ++j) {
+        const int d0 = j * Dc, d1 = std::min(D, d0 + Dc);
+        if (d0 >= d1) break;
+        // output plane d taps source planes floor(d + tz) - halo + 1 ... floor(d + tz) + halo
+        const double hi = std::floor((double)(d1 - 1) + m[3]) + halo;
+        const double lo = std::floor((double)d0 + m[3]) - halo;
+        if (hi >= 0.0 && lo <= (double)(D - 1)) {
+            const int c_hi = (int)(std::min(hi, (double)(D - 1)) / Dc);
+            VT_HIPP(hipStreamWaitEvent(v->stream, ev_up[(size_t)c_hi], 0));
+        }
+        v->out_plane0 = d0;
+        v->oD = d1 - d0;
+        static const int dbg = std::getenv("VT_PIPE_DBG") ? std::atoi(std::getenv("VT_PIPE_DBG")) : 0;
+        if (dbg == 1) rc = 0;                                                     // no kernel at all
+        else if (dbg == 2) { rc = 0; (void)hipMemsetAsync(d_out + (size_t)d0 * H * W, 0, (size_t)(d1 - d0) * H * W * 4, v->stream); }   // a fill kernel instead
+        else rc = do_affine(v, m, d_out + (size_t)d0 * H * W, lflags);
+        v->out_plane0 = 0;
+        v->oD = D;
+        if (rc) return finish(rc);
+        VT_HIPP(hipEventRecord(ev_k[(size_t)j], v->stream));
+    }
+    // downloads: each one is queued when its slab is done (host wait -- the calling thread has nothing else to do)
+    for (int j = 0; j < nch; ++j) {
+        const int d0 = j * Dc, d1 = std::min(D, d0 + Dc);
+        if (d0 >= d1) break;
+        VT_HIPP(hipEventSynchronize(ev_k[(size_t)j]));
+        VT_HIPP(hipMemcpyAsync(h_out + (size_t)d0 * H * W, d_out + (size_t)d0 * H * W, (size_t)(d1 - d0) * H * W * sizeof(float),
+                               hipMemcpyDeviceToHost, s_dn));
+        if (trace) VT_HIPP(hipEventRecord(ev_dn[(size_t)j], s_dn));
+    }
+    const double t_slabs = now_ms();
+    VT_HIPP(hipStreamSynchronize(s_dn));
+    if (trace) {
+        const double t_done = now_ms();
+        std::fprintf(stderr, "[pipe] host: create %.2f  alloc+pin %.2f  enqueue uploads %.2f  enqueue slabs %.2f  drain %.2f  total %.2f ms\n",
+                     t_created - t_begin, t_pinned - t_created, t_uploads - t_pinned, t_slabs - t_uploads, t_done - t_slabs, t_done - t_begin);
+        for (int k = 0; k < nch; ++k) {
+            float a = 0, b = 0, c = 0;
+            hipEventElapsedTime(&a, ev_up[0], ev_up[(size_t)k]);
+            hipEventElapsedTime(&b, ev_up[0], ev_k[(size_t)k]);
+            hipEventElapsedTime(&c, ev_up[0], ev_dn[(size_t)k]);
+            std::fprintf(stderr, "[pipe] chunk %2d: upload done %+7.2f  kernel done %+7.2f  download done %+7.2f ms\n", k, a, b, c);
+        }
+    }
+#undef VT_HIPP
+    return finish(0);
+}
+
 // n transforms of one resident volume in one call.  Small volumes (the launch-latency regime: template
 // rotations, sub-tomogram alignment) take ONE launch of the batched direct kernel, 65535 matrices at a time; larger
 // ones are queued back to back on the handle's stream without returning to the caller in between.
@@ -1398,6 +1589,24 @@ int vt_host_register(int dev, void* ptr, size_t bytes)
     return 0;
 }
 
+int vt_device_trim(int dev)
+{
+    if (dev < 0 || dev >= 64) return fail(VT_ENODEV, "device index %d", dev);
+    int rc = use_device(dev);
+    if (rc) return rc;
+    std::vector<std::pair<size_t, void*>> drop, drop_small;
+    {
+        std::lock_guard<std::mutex> lk(g_cache[dev].mu);
+        drop.swap(g_cache[dev].big);
+        g_cache[dev].big_bytes = 0;
+        drop_small.swap(g_cache[dev].bufs);
+        g_cache[dev].buf_bytes = 0;
+    }
+    for (auto& d : drop) (void)hipFree(d.second);
+    for (auto& d : drop_small) (void)hipFree(d.second);
+    return 0;
+}
+
 int vt_host_unregister(int dev, void* ptr)
 {
     if (!ptr) return 0;
@@ -1567,11 +1776,9 @@ int vt_prefilter_inplace(int dev, float* d_volume, int D, int H, int W)
 }
 
 // One-shot transform of a host volume into a host buffer (transforms.py:164-226): upload, prefilter, transform, download.
-// PCIe-bound (512^3: 2 x 10 ms of copies around < 1.5 ms of kernels).  A slab pipeline built from slab handles and two host
-// threads (upload of one slab against the download of another) was measured SLOWER (512^3 linear 24.9 vs 20.2 ms, filt 38.5
-// vs 21.9 with hipMalloc/hipFree per slab; 27.2 vs 19.8 and 21.4 vs 21.5 once the slab buffers were recycled): the uploads
-// and downloads of the two threads do not overlap in practice (pitched 2-D uploads, blocking streams).  Duplex overlap needs one
-// resident buffer filled progressively on a copy stream with per-slab launches gated by events -- open.
+// PCIe-bound (512^3: 2 x 9.4 ms of copies around < 1.5 ms of kernels).  Where the output planes only need nearby source
+// planes (axis-0-separable matrices, no prefilter) the call is pipelined so that both PCIe directions run at once
+// (oneshot_pipelined below); everything else is the plain sequence.
 int vt_affine_oneshot(int dev, const float* h_volume, int D, int H, int W, int interp, const float* m4x4,
                       float* h_out, int flags, float* elapsed_ms)
 {
@@ -1583,8 +1790,12 @@ int vt_affine_oneshot(int dev, const float* h_volume, int D, int H, int W, int i
     VT_HIP(hipEventCreate(&t1));
     hipEventRecord(t0, nullptr);
     vt_volume_t* v = nullptr;
-    rc = vt_volume_create(dev, D, H, W, interp, h_volume, 0, &v);
-    if (!rc) rc = vt_volume_affine(v, m4x4, h_out, flags & ~VT_OUT_DEVICE);
+    static const bool no_pipe = std::getenv("VT_ONESHOT_SEQ") != nullptr;      // A/B switch: always the plain sequence
+    rc = no_pipe ? 1 : oneshot_pipelined(dev, h_volume, D, H, W, interp, m4x4, h_out, flags & ~VT_OUT_DEVICE);
+    if (rc == 1) {
+        rc = vt_volume_create(dev, D, H, W, interp, h_volume, 0, &v);
+        if (!rc) rc = vt_volume_affine(v, m4x4, h_out, flags & ~VT_OUT_DEVICE);
+    }
     hipEventRecord(t1, nullptr);
     hipEventSynchronize(t1);
     if (elapsed_ms) hipEventElapsedTime(elapsed_ms, t0, t1);
