@@ -395,6 +395,20 @@ def test_oneshot_matches_resident_path(interp):
     sv.close()
 
 
+@pytest.mark.parametrize('interp', ['linear', 'filt_bspline', 'filt_bspline_simple'])
+def test_oneshot_pipeline_ragged_chunks(interp):
+    """The pipelined one-shot (chunked upload, per-chunk prefilter passes, per-slab transform, chunked download) on a depth
+    that the chunk count does not divide and that has a short last prefilter chunk, against the oracle; translations that
+    make the first / last output slabs depend on far-away or on no source planes."""
+    shape = (100, 300, 290)                       # 34.8 MB: above the pipeline threshold; 8 chunks of 13 planes, the last of 9
+    vol = rand_vol(shape, 23)
+    for m in (vt.utils.transform_matrix(rotation=(0, 20, 0), translation=(3.25, -1.0, 2.0), center=centre(shape)),
+              vt.utils.translation_matrix((-30.5, 0.0, 1.0)), vt.utils.translation_matrix((61.0, 2.5, 0.0)),
+              vt.utils.translation_matrix((150.0, 0.0, 0.0))):
+        got = vt.affine(vol, m, interpolation=interp, device='gpu')
+        assert np.abs(got - oracle.affine(vol, m, interp)).max() <= TOL[interp], interp
+
+
 @pytest.mark.parametrize('interp', ['linear', 'bspline', 'filt_bspline'])
 def test_output_shape_other_than_source_shape(interp):
     """vt_volume_set_output_shape (scipy's output_shape, transforms.py:136-150): every kernel family with an output grid

@@ -1178,13 +1178,19 @@ int create_common(int dev, int D, int H, int W, int interp, const float* data, i
 // has arrived (stream waits on the upload events); every finished slab is downloaded on a second non-blocking copy stream
 // while later chunks are still going up.  The sequence is the one of tools/probes/pipeline_probe.hip (512^3: 12.3 ms
 // against 19.8 ms sequential).  Requirements: an axis-0-separable matrix (each output plane taps a window of source
-// planes), an interpolation without prefilter (the z pass of the prefilter needs every plane), only the plain resident
-// layout (the secondary copies are built from a complete source).  Returns 1 when the call does not qualify.
+// planes), only the plain resident layout (the secondary copies are built from a complete source).  filt_* interpolations:
+// the X and Y passes of the prefilter are plane-local and run per uploaded chunk; the axis-0 pass already works in chunks
+// of 64 / 128 planes with 16 planes of warm-up, so each of its chunks is launched as soon as those planes are there (same
+// kernels, same chunk grid: the coefficients are the resident volume's, bit for bit).  Returns 1 when the call does not
+// qualify.
 int oneshot_pipelined(int dev, const float* h_volume, int D, int H, int W, int interp, const float* m4x4, float* h_out, int flags)
 {
     const size_t n = (size_t)D * H * W;
-    if (is_filtered(interp) || (flags & (VT_KEEP_OUTSIDE | VT_FORCE_DIRECT | VT_NO_ZSEP | VT_NO_MARCH)) || n * sizeof(float) < ((size_t)32 << 20) || D < 32)
+    if ((flags & (VT_KEEP_OUTSIDE | VT_FORCE_DIRECT | VT_NO_ZSEP | VT_NO_MARCH)) || n * sizeof(float) < ((size_t)32 << 20) || D < 32)
         return 1;
+    const bool filt = is_filtered(interp);
+    // prefilter passes as run_prefilter orders them for such a volume: X in place, Y into the partner buffer, Z back
+    if (filt && (W > 2048 || prefilter_axis_in_place_ok(1, D, H, W) || prefilter_axis_in_place_ok(0, D, H, W))) return 1;
     double m[16];
     for (int i = 0; i < 16; ++i) m[i] = (double)m4x4[i];
     if (!(m[0] == 1.0 && m[1] == 0.0 && m[2] == 0.0 && m[4] == 0.0 && m[8] == 0.0 && std::fabs(m[3]) < 1.0e9)) return 1;
@@ -1219,6 +1225,8 @@ int oneshot_pipelined(int dev, const float* h_volume, int D, int H, int W, int i
     hipStream_t own_stream = v->stream;           // the slab launches go to the pipeline's kernel stream
     v->stream = s_k;
     float* d_out = nullptr;
+    float* d_tmp = nullptr;                        // prefilter ping-pong partner (filt_* only)
+    const size_t src_bytes = (size_t)D * H * v->P * sizeof(float);
     int nch = D >= 256 ? 16 : 8;
     if (const char* e = std::getenv("VT_PIPE_NCH")) nch = std::max(1, std::min(D / 2, std::atoi(e)));
     const int Dc = (D + nch - 1) / nch;
@@ -1232,6 +1240,7 @@ int oneshot_pipelined(int dev, const float* h_volume, int D, int H, int W, int i
         for (hipEvent_t e : ev_k) if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : ev_dn) if (e) (void)hipEventDestroy(e);
         cached_free(dev, d_out, n * sizeof(float));
+        cached_free(dev, d_tmp, src_bytes);
         vt_volume_destroy(v);
         return code;
     };
@@ -1241,6 +1250,7 @@ int oneshot_pipelined(int dev, const float* h_volume, int D, int H, int W, int i
         if (e_ != hipSuccess) return finish(fail((int)e_, "%s: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__)); \
     } while (0)
     VT_HIPP(cached_malloc(dev, reinterpret_cast<void**>(&d_out), n * sizeof(float)));
+    if (filt) VT_HIPP(cached_malloc(dev, reinterpret_cast<void**>(&d_tmp), src_bytes));
     // dependency-only events (no timestamps) unless the timeline is being traced
     const unsigned evflags = trace ? hipEventDefault : hipEventDisableTiming;
     for (int k = 0; k < nch; ++k) {
@@ -1261,31 +1271,49 @@ int oneshot_pipelined(int dev, const float* h_volume, int D, int H, int W, int i
     const double t_uploads = now_ms();
     const int halo = is_cubic(interp) ? 2 : 1;
     const int lflags = (flags | VT_OUT_DEVICE | VT_NO_ZPAIR | VT_NO_RSWAP) & ~VT_KEEP_OUTSIDE;
-    for (int j = 0; j < nch; ++j) {
-        const int d0 = j * Dc, d1 = std::min(D, d0 + Dc);
-        if (d0 >= d1) break;
-        // output plane d taps source planes floor(d + tz) - halo + 1 ... floor(d + tz) + halo
-        const double hi = std::floor((double)(d1 - 1) + m[3]) + halo;
-        const double lo = std::floor((double)d0 + m[3]) - halo;
-        if (hi >= 0.0 && lo <= (double)(D - 1)) {
-            const int c_hi = (int)(std::min(hi, (double)(D - 1)) / Dc);
-            VT_HIPP(hipStreamWaitEvent(v->stream, ev_up[(size_t)c_hi], 0));
+    // Kernel stream, per uploaded chunk: (filt_*) X and Y passes of the prefilter on the chunk's planes (plane-local), then
+    // every axis-0 chunk of the prefilter whose input planes (its own + warm-up) are there, then every output slab whose
+    // source planes are final.  The prefilter runs the same kernels on the same chunk grid as for a resident volume.
+    const int zC = filt ? prefilter_chunk_size(D) : 1;
+    const int nzc = filt ? (D + zC - 1) / zC : 0;
+    int z_chunks_done = 0, next_slab = 0;
+    const int nslabs = (D + Dc - 1) / Dc;
+    for (int k = 0; k < nch; ++k) {
+        const int z0 = k * Dc, z1 = std::min(D, z0 + Dc);
+        if (z0 >= z1) break;
+        VT_HIPP(hipStreamWaitEvent(s_k, ev_up[(size_t)k], 0));
+        int final_planes = z1;                     // source planes [0, final_planes) hold what the transform samples
+        if (filt) {
+            const size_t off = (size_t)z0 * H * v->P;
+            VT_HIPP(launch_prefilter_axis(2, v->d_src + off, v->d_src + off, z1 - z0, H, W, v->P, false, s_k));
+            VT_HIPP(launch_prefilter_axis(1, v->d_src + off, d_tmp + off, z1 - z0, H, W, v->P, false, s_k));
+            int c1 = z_chunks_done;
+            while (c1 < nzc && std::min(D, (c1 + 1) * zC + prefilter_warmup()) <= z1) ++c1;
+            if (c1 > z_chunks_done) {
+                VT_HIPP(launch_prefilter_axis0_chunks(d_tmp, v->d_src, D, H, W, v->P, z_chunks_done, c1, s_k));
+                z_chunks_done = c1;
+            }
+            final_planes = std::min(D, z_chunks_done * zC);
         }
-        v->out_plane0 = d0;
-        v->oD = d1 - d0;
-        static const int dbg = std::getenv("VT_PIPE_DBG") ? std::atoi(std::getenv("VT_PIPE_DBG")) : 0;
-        if (dbg == 1) rc = 0;                                                     // no kernel at all
-        else if (dbg == 2) { rc = 0; (void)hipMemsetAsync(d_out + (size_t)d0 * H * W, 0, (size_t)(d1 - d0) * H * W * 4, v->stream); }   // a fill kernel instead
-        else rc = do_affine(v, m, d_out + (size_t)d0 * H * W, lflags);
-        v->out_plane0 = 0;
-        v->oD = D;
-        if (rc) return finish(rc);
-        VT_HIPP(hipEventRecord(ev_k[(size_t)j], v->stream));
+        while (next_slab < nslabs) {
+            const int d0 = next_slab * Dc, d1 = std::min(D, d0 + Dc);
+            // output plane d taps source planes floor(d + tz) - halo + 1 ... floor(d + tz) + halo
+            const double hi = std::floor((double)(d1 - 1) + m[3]) + halo;
+            if (std::min(hi, (double)(D - 1)) >= (double)final_planes) break;          // wait for more planes
+            v->out_plane0 = d0;
+            v->oD = d1 - d0;
+            rc = do_affine(v, m, d_out + (size_t)d0 * H * W, lflags);
+            v->out_plane0 = 0;
+            v->oD = D;
+            if (rc) return finish(rc);
+            VT_HIPP(hipEventRecord(ev_k[(size_t)next_slab], s_k));
+            ++next_slab;
+        }
     }
+    if (next_slab < nslabs) return finish(fail(VT_EINVAL, "one-shot pipeline left %d slabs unlaunched", nslabs - next_slab));
     // downloads: each one is queued when its slab is done (host wait -- the calling thread has nothing else to do)
-    for (int j = 0; j < nch; ++j) {
+    for (int j = 0; j < nslabs; ++j) {
         const int d0 = j * Dc, d1 = std::min(D, d0 + Dc);
-        if (d0 >= d1) break;
         VT_HIPP(hipEventSynchronize(ev_k[(size_t)j]));
         VT_HIPP(hipMemcpyAsync(h_out + (size_t)d0 * H * W, d_out + (size_t)d0 * H * W, (size_t)(d1 - d0) * H * W * sizeof(float),
                                hipMemcpyDeviceToHost, s_dn));

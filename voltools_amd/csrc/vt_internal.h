@@ -218,6 +218,9 @@ hipError_t init_affine_kernels();   // raises the dynamic-LDS limit of every til
 // axis: 0 (Z, stride H*W), 1 (Y, stride W), 2 (X, contiguous).
 hipError_t launch_prefilter_axis(int axis, const float* src, float* dst, int D, int H, int W, int pitch,
                                  bool lo_interior, hipStream_t stream);
+int prefilter_chunk_size(int N);                  // samples per chunk of the strided passes on lines of N samples
+int prefilter_warmup();                           // samples of warm-up on each side of a chunk
+hipError_t launch_prefilter_axis0_chunks(const float* src, float* dst, int D, int H, int W, int pitch, int c0, int c1, hipStream_t stream);
 bool prefilter_axis_in_place_ok(int axis, int D, int H, int W);
 
 }  // namespace vt

@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void prefilter_chunked(const float* __restrict
                                                           int N, int64_t es,          // line length, element stride
                                                           int nA, int64_t sA,         // lane axis (coalesced)
                                                           int nB, int64_t sB,         // outer axis
-                                                          int nchunks, int lo_interior)
+                                                          int nchunks, int lo_interior, int chunk0)
 {
     static_assert(C >= K && K >= 12, "chunk geometry");
     constexpr int R = C + 2 * K;
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void prefilter_chunked(const float* __restrict
     const int ab = (int)(gw % nAb);
     const int64_t rest = gw / nAb;
     const int bi = (int)(rest % nB);
-    const int chunk = (int)(rest / nB);
+    const int chunk = chunk0 + (int)(rest / nB);     // chunk0: first chunk of this launch (axis-0 pass of the one-shot pipeline)
     if (chunk >= nchunks) return;                     // wave-uniform
 
     const int ai = ab * 64 + lane;
@@ -312,6 +312,40 @@ __global__ __launch_bounds__(256) void prefilter_chunked(const float* __restrict
 constexpr int kChunk = 64, kWarm = 16;
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
+// [measured] 128-sample chunks (1.25x read overlap, 160 data registers): 512^3 0.82 vs 0.85 ms, 1024^3 6.4 vs 6.95 ms
+int prefilter_chunk_size(int N)
+{
+    const int variant = env_int("VT_PF_CHUNK", N >= 256 ? 128 : 64);
+    return (variant == 128) ? 128 : (variant == 32 ? 32 : kChunk);
+}
+
+// chunks [c0, c1) of every line (all of them for the ordinary passes; a range for the axis-0 pass of the one-shot pipeline,
+// which filters a chunk as soon as the planes it reads -- its own and kWarm on each side -- are there; same chunk grid,
+// same bits)
+static hipError_t launch_chunked(int C, const float* src, float* dst, int N, int64_t es, int nA, int64_t sA, int nB, int64_t sB,
+                                 int c0, int c1, bool lo_interior, hipStream_t stream)
+{
+    const int nchunks = (N + C - 1) / C;
+    c1 = c1 < nchunks ? c1 : nchunks;
+    if (c0 < 0 || c0 >= c1) return hipSuccess;
+    const int64_t waves = (int64_t)((nA + 63) / 64) * nB * (c1 - c0);
+    const int64_t blocks = (waves + 3) / 4;
+    if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    // the kernel bounds its chunk index by `nchunks`: pass the end of the range
+    if (C == 128)
+        hipLaunchKernelGGL((prefilter_chunked<128, kWarm>), dim3((unsigned)blocks), dim3(256), 0, stream,
+                           src, dst, N, es, nA, sA, nB, sB, c1, lo_interior ? 1 : 0, c0);
+    else if (C == 32)
+        hipLaunchKernelGGL((prefilter_chunked<32, kWarm>), dim3((unsigned)blocks), dim3(256), 0, stream,
+                           src, dst, N, es, nA, sA, nB, sB, c1, lo_interior ? 1 : 0, c0);
+    else
+        hipLaunchKernelGGL((prefilter_chunked<kChunk, kWarm>), dim3((unsigned)blocks), dim3(256), 0, stream,
+                           src, dst, N, es, nA, sA, nB, sB, c1, lo_interior ? 1 : 0, c0);
+    return hipGetLastError();
+}
+
+int prefilter_warmup() { return kWarm; }
+
 bool prefilter_axis_in_place_ok(int axis, int D, int H, int W)
 {
     if (axis == 2) return W <= 2048;                  // whole line in registers before any store
@@ -358,23 +392,14 @@ hipError_t launch_prefilter_axis(int axis, const float* src, float* dst, int D, 
     if (axis == 2) { N = W; es = 1; nA = H; sA = pitch; nB = D; sB = plane; }      // very wide lines: lanes along y
     else if (axis == 1) { N = H; es = pitch; nA = W; sA = 1; nB = D; sB = plane; }
     else { N = D; es = plane; nA = W; sA = 1; nB = H; sB = pitch; }
-    // [measured] 128-sample chunks (1.25x read overlap, 160 data registers): 512^3 0.82 vs 0.85 ms, 1024^3 6.4 vs 6.95 ms
-    const int variant = env_int("VT_PF_CHUNK", N >= 256 ? 128 : 64);
-    const int C = (variant == 128) ? 128 : (variant == 32 ? 32 : kChunk);
-    const int nchunks = (N + C - 1) / C;
-    const int64_t waves = (int64_t)((nA + 63) / 64) * nB * nchunks;
-    const int64_t blocks = (waves + 3) / 4;
-    if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    if (C == 128)
-        hipLaunchKernelGGL((prefilter_chunked<128, kWarm>), dim3((unsigned)blocks), dim3(256), 0, stream,
-                           src, dst, N, es, nA, sA, nB, sB, nchunks, lo_interior ? 1 : 0);
-    else if (C == 32)
-        hipLaunchKernelGGL((prefilter_chunked<32, kWarm>), dim3((unsigned)blocks), dim3(256), 0, stream,
-                           src, dst, N, es, nA, sA, nB, sB, nchunks, lo_interior ? 1 : 0);
-    else
-        hipLaunchKernelGGL((prefilter_chunked<kChunk, kWarm>), dim3((unsigned)blocks), dim3(256), 0, stream,
-                           src, dst, N, es, nA, sA, nB, sB, nchunks, lo_interior ? 1 : 0);
-    return hipGetLastError();
+    const int C = prefilter_chunk_size(N);
+    return launch_chunked(C, src, dst, N, es, nA, sA, nB, sB, 0, (N + C - 1) / C, lo_interior, stream);
+}
+
+hipError_t launch_prefilter_axis0_chunks(const float* src, float* dst, int D, int H, int W, int pitch, int c0, int c1, hipStream_t stream)
+{
+    const int C = prefilter_chunk_size(D);
+    return launch_chunked(C, src, dst, D, (int64_t)H * pitch, W, 1, H, pitch, c0, c1, false, stream);
 }
 
 }  // namespace vt
