@@ -512,11 +512,11 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
                     slot_floats = vecs * 4;
                     if (vecs > vec_max) continue;
                 } else if (L[1] * (L[2] / 2) > vec_max) continue;
-                // planes with more tiles than the chip keeps resident: one more pair in flight where three slots still
+                // planes with far more tiles than the chip keeps resident: one more pair in flight where three slots still
                 // leave three workgroups per CU ([measured] 1024^3: 2.020 -> 1.972 ms at 0 degrees, 2.221 -> 2.202 at 30;
                 // 512^3, whole layers resident: 0.258 -> 0.263, so not there)
                 if (v->tune.la <= 0 && la == 1 && 9LL * slot_floats * 4 <= 160 * 1024 &&
-                    (int64_t)((v->oH + th - 1) / th) * ((v->oW + tw - 1) / tw) > 3LL * v->cu_count)
+                    (int64_t)((v->oH + th - 1) / th) * ((v->oW + tw - 1) / tw) > 7LL * v->cu_count)    // 640^3, 768^3: -2..-4 % with it
                     la = 2;
                 const int64_t bytes = std::max<int64_t>((int64_t)(la + 1) * slot_floats * 4, zp_box ? 0 : march_table_bytes());
                 if (bytes > v->lds_limit) continue;
