@@ -407,6 +407,12 @@ def test_oneshot_pipeline_ragged_chunks(interp):
               vt.utils.translation_matrix((150.0, 0.0, 0.0))):
         got = vt.affine(vol, m, interpolation=interp, device='gpu')
         assert np.abs(got - oracle.affine(vol, m, interp)).max() <= TOL[interp], interp
+    # result written over the input: must not be pipelined (slabs would land on planes not yet uploaded)
+    m = vt.utils.translation_matrix((-30.5, 0.0, 1.0))
+    want = oracle.affine(vol, m, interp)
+    inout = vol.copy()
+    vt.affine(inout, m, interpolation=interp, device='gpu', output=inout)
+    assert np.abs(inout - want).max() <= TOL[interp], interp
 
 
 @pytest.mark.parametrize('interp', ['linear', 'bspline', 'filt_bspline'])

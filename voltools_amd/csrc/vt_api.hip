@@ -1188,6 +1188,10 @@ int oneshot_pipelined(int dev, const float* h_volume, int D, int H, int W, int i
     const size_t n = (size_t)D * H * W;
     if ((flags & (VT_KEEP_OUTSIDE | VT_FORCE_DIRECT | VT_NO_ZSEP | VT_NO_MARCH)) || n * sizeof(float) < ((size_t)32 << 20) || D < 32)
         return 1;
+    {   // result written over the input (output=volume): slabs would be downloaded over planes still waiting to be uploaded
+        const uintptr_t a0 = reinterpret_cast<uintptr_t>(h_volume), b0 = reinterpret_cast<uintptr_t>(h_out);
+        if (a0 < b0 + n * sizeof(float) && b0 < a0 + n * sizeof(float)) return 1;
+    }
     const bool filt = is_filtered(interp);
     // prefilter passes as run_prefilter orders them for such a volume: X in place, Y into the partner buffer, Z back
     if (filt && (W > 2048 || prefilter_axis_in_place_ok(1, D, H, W) || prefilter_axis_in_place_ok(0, D, H, W))) return 1;
