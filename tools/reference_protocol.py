@@ -26,13 +26,13 @@ def protocol(n, nrot=100):
         sv.synchronize()
         row['static_vol_out_ms'] = round((time.perf_counter() - t0) / nrot * 1e3, 4)          # README 'static_vol_affine_out'
         t0 = time.perf_counter()
-        for m in mats[:30]:
+        for m in mats:
             sv.affine(m)
-        row['static_vol_ms'] = round((time.perf_counter() - t0) / 30 * 1e3, 4)                 # README 'static_vol_affine'
+        row['static_vol_ms'] = round((time.perf_counter() - t0) / nrot * 1e3, 4)                 # README 'static_vol_affine'
         t0 = time.perf_counter()
-        for m in mats[:20]:
+        for m in mats:                                # all 100, first call included, as the reference averages them
             vt.affine(data, m, interpolation=interp, device='gpu')
-        row['np_transform_ms'] = round((time.perf_counter() - t0) / 20 * 1e3, 4)               # README 'transforms_affine' numpy in/out
+        row['np_transform_ms'] = round((time.perf_counter() - t0) / nrot * 1e3, 4)               # README 'transforms_affine' numpy in/out
         outs = vt.empty((nrot, n, n, n), device='gpu:0') if n <= 100 else None
         if outs is not None:
             mm = np.stack(mats)

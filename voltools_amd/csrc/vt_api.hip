@@ -175,12 +175,23 @@ void cached_free(int dev, void* p, size_t bytes)
         return;
     }
     if (dev < 64 && bytes <= kCacheBufMax) {
-        std::lock_guard<std::mutex> lk(g_cache[dev].mu);
-        if (g_cache[dev].bufs.size() < 16 && g_cache[dev].buf_bytes + bytes <= kCacheTotalMax) {
-            g_cache[dev].bufs.emplace_back(bytes, p);
+        // most recently released last; when the cache is full the oldest entries make room (a cache that only ever kept its
+        // first 16 buffers sent every later size to hipMalloc / hipFree: 0.24 -> 0.7 ms per one-shot call at 100^3 after a
+        // run over other sizes)
+        std::vector<void*> drop;
+        {
+            std::lock_guard<std::mutex> lk(g_cache[dev].mu);
+            auto& b = g_cache[dev].bufs;
+            b.emplace_back(bytes, p);
             g_cache[dev].buf_bytes += bytes;
-            return;
+            while (!b.empty() && (b.size() > 16 || g_cache[dev].buf_bytes > kCacheTotalMax)) {
+                drop.push_back(b.front().second);
+                g_cache[dev].buf_bytes -= b.front().first;
+                b.erase(b.begin());
+            }
         }
+        for (void* d : drop) (void)hipFree(d);
+        return;
     }
     (void)hipFree(p);
 }
