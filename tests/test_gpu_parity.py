@@ -395,6 +395,18 @@ def test_oneshot_matches_resident_path(interp):
     sv.close()
 
 
+@pytest.mark.parametrize('interp', ['linear', 'bspline', 'filt_bspline'])
+def test_oneshot_pipeline_thin_volume(interp):
+    """Pipelined one-shot on a thin volume: 8 chunks of 5 planes, one axis-0 prefilter chunk (it can only run when every plane
+    is there), output slabs that need planes of several upload chunks."""
+    shape = (40, 512, 520)                        # 42.6 MB
+    vol = rand_vol(shape, 29)
+    for m in (vt.utils.transform_matrix(rotation=(0, -50, 0), translation=(7.5, 3.0, -2.0), center=centre(shape)),
+              vt.utils.translation_matrix((-12.25, 0.0, 0.0))):
+        got = vt.affine(vol, m, interpolation=interp, device='gpu')
+        assert np.abs(got - oracle.affine(vol, m, interp)).max() <= TOL[interp], interp
+
+
 @pytest.mark.parametrize('interp', ['linear', 'filt_bspline', 'filt_bspline_simple'])
 def test_oneshot_pipeline_ragged_chunks(interp):
     """The pipelined one-shot (chunked upload, per-chunk prefilter passes, per-slab transform, chunked download) on a depth
