@@ -10,9 +10,66 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <unordered_map>
 #include <vector>
 
 using namespace vt;
+
+// ---- VT_DEBUG_GUARD=1: every device allocation of this library gets 1 MiB of NaN (0xFF bytes) in front of it and behind
+// it.  A kernel that reads out of bounds then produces NaN (parity tests fail instead of passing on whatever the neighbouring
+// allocation held, or faulting when the neighbour has been freed); one that writes out of bounds is caught when the buffer
+// is released (message + abort).  A poor man's address sanitizer for the GPU side (the real one is not available here). ----
+namespace vt_guard {
+constexpr size_t kGuard = (size_t)1 << 20;
+struct Entry { void* base; size_t bytes; };
+static std::mutex mu;
+static std::unordered_map<void*, Entry> live;
+static bool enabled()
+{
+    static const bool on = std::getenv("VT_DEBUG_GUARD") != nullptr;
+    return on;
+}
+static hipError_t alloc(void** p, size_t bytes)
+{
+    if (!enabled()) return hipMalloc(p, bytes);
+    char* base = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&base), bytes + 2 * kGuard);
+    if (e != hipSuccess) return e;
+    (void)hipMemset(base, 0xFF, kGuard);
+    (void)hipMemset(base + kGuard + bytes, 0xFF, kGuard);
+    (void)hipDeviceSynchronize();
+    *p = base + kGuard;
+    std::lock_guard<std::mutex> lk(mu);
+    live[*p] = Entry{base, bytes};
+    return hipSuccess;
+}
+static hipError_t release(void* p)
+{
+    if (!enabled() || !p) return hipFree(p);
+    Entry en{nullptr, 0};
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = live.find(p);
+        if (it == live.end()) return hipFree(p);
+        en = it->second;
+        live.erase(it);
+    }
+    (void)hipDeviceSynchronize();
+    std::vector<unsigned char> h(2 * kGuard);
+    (void)hipMemcpy(h.data(), en.base, kGuard, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(h.data() + kGuard, static_cast<char*>(en.base) + kGuard + en.bytes, kGuard, hipMemcpyDeviceToHost);
+    for (size_t i = 0; i < 2 * kGuard; ++i)
+        if (h[i] != 0xFF) {
+            std::fprintf(stderr, "[vt guard] out-of-bounds WRITE %s a device buffer of %zu bytes (guard offset %zu)\n",
+                         i < kGuard ? "in front of" : "behind", en.bytes, i < kGuard ? kGuard - i : i - kGuard);
+            std::fflush(stderr);
+            std::abort();
+        }
+    return hipFree(en.base);
+}
+}  // namespace vt_guard
+#define hipMalloc(p, n) vt_guard::alloc(reinterpret_cast<void**>(p), (n))
+#define hipFree(p) vt_guard::release(p)
 
 namespace {
 
