@@ -1,0 +1,15 @@
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import voltools_amd as vt
+n = 512
+data = np.random.RandomState(1).random_sample((n, n, n)).astype(np.float32)
+m = vt.utils.transform_matrix(rotation=(0, 33, 0), translation=(1.5, 2, -3), center=np.divide((n, n, n), 2))
+for interp in ('linear', 'filt_bspline'):
+    ts = []
+    for _ in range(24):
+        t0 = time.perf_counter()
+        r = vt.affine(data, m, interpolation=interp, device='gpu')
+        ts.append((time.perf_counter() - t0) * 1e3)
+        del r
+    print(interp, ' '.join(f'{t:.1f}' for t in ts))
