@@ -10,7 +10,8 @@ for n in (250, 512):
     for mname, m in (('general', vt.utils.transform_matrix(rotation=(10, 20, 30), rotation_order='sxyz', center=c)),
                      ('axis0', vt.utils.transform_matrix(rotation=(0, 33, 0), translation=(1.5, 2, -3), center=c))):
         for interp in ('linear', 'filt_bspline'):
-            vt.affine(data, m, interpolation=interp, device='gpu')
+            for _ in range(3):                    # warm-up while holding a result: the pool then owns both buffers the loop alternates between
+                r = vt.affine(data, m, interpolation=interp, device='gpu')
             t0 = time.perf_counter()
             for _ in range(5):
                 r = vt.affine(data, m, interpolation=interp, device='gpu')
