@@ -776,8 +776,10 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
     }
     // general matrices: packed 3-D footprints (kind 6) when the linear part is invertible
     // Bounding boxes are cheaper to address (no row table), so the packed form must stage clearly less to win:
-    // measured cross-over at ~0.6x (trilinear) / ~0.5x (cubic) of the box bytes per voxel (512^3).
-    if (!zsep && !(flags & VT_NO_PACKED)) {
+    // measured cross-over at ~0.6x of the box bytes per voxel for trilinear (512^3).  Cubic: since both kernels gather
+    // with 8-byte reads the boxes win at every size ([measured] rotation (25,-40,70): 250^3 0.177 vs 0.198 ms, 384^3 0.563 vs
+    // 0.604, 512^3 1.295 vs 1.328), so the packed form is only planned for trilinear (or when forced).
+    if (!zsep && !(flags & VT_NO_PACKED) && (!cubic || (flags & VT_FORCE_PACKED))) {
         const double A[9] = {m[0], m[1], m[2], m[4], m[5], m[6], m[8], m[9], m[10]};
         const double det = A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6]) + A[2] * (A[3] * A[7] - A[4] * A[6]);
         double amax = 0;
