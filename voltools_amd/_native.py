@@ -216,12 +216,19 @@ class _HostResultPool:
     (tools/pcie_probe.py).  Results therefore come from a small pool of host buffers that stay faulted-in and
     registered with the HIP runtime: a buffer is handed out again once the caller has dropped every array that
     views it (reference count of the owner back at the pool's own).  Arrays the caller keeps are never reused.
-    ``VT_HOST_POOL=0`` disables the pool; ``VT_HOST_POOL_MB`` caps it (default 4096)."""
+    ``VT_HOST_POOL=0`` disables the pool; ``VT_HOST_POOL_MB`` caps it (default: a tenth of the machine's memory, between
+    4 and 64 GiB -- a loop over 1024^3 one-shot results alternates between two 4-GiB buffers: 94 ms per call with both in the
+    pool, 250 ms when one of them is a fresh allocation every time)."""
 
     def __init__(self):
         self.entries = []          # owner arrays (1-D float32), most recently used last
         self.enabled = os.environ.get('VT_HOST_POOL', '1') != '0'
-        self.cap = int(os.environ.get('VT_HOST_POOL_MB', '4096')) << 20
+        try:
+            phys_mb = (os.sysconf('SC_PAGE_SIZE') * os.sysconf('SC_PHYS_PAGES')) >> 20
+        except (ValueError, OSError, AttributeError):
+            phys_mb = 0
+        default_mb = min(65536, max(4096, phys_mb // 10))
+        self.cap = int(os.environ.get('VT_HOST_POOL_MB', str(default_mb))) << 20
         self.min_bytes = 1 << 20   # small results are not worth a pool slot
         # reference count of an owner that nobody outside the pool refers to, measured by the scan itself
         self._idle = self._scan([np.empty(1, dtype=np.float32)], 1, calibrate=True)
