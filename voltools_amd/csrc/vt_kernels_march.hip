@@ -409,7 +409,7 @@ __global__ __launch_bounds__(NT) void affine_march_zsep(const float* __restrict_
                 if constexpr (FAST) {
                     if (!no_stores) {
 #pragma unroll
-                        for (int px = 0; px < NPIX; ++px) out[ooff[px] + dofs + i * ostride] = val[px];
+                        for (int px = 0; px < NPIX; ++px) __builtin_nontemporal_store(val[px], &out[ooff[px] + dofs + i * ostride]);
                     } else if (val[0] == 12345.678f) out[0] = val[0];           // keep the values alive
                 } else {
                     const int d = d_begin + g * G + i;
@@ -799,11 +799,13 @@ __global__ __launch_bounds__(NT) VT_ZPAIR_OCC void affine_march_zpair(const floa
                     for (int px = 0; px < NPIX; ++px) asm volatile("" ::"v"(val[px]));
                 } else if (FAST) {
 #pragma unroll
-                    for (int px = 0; px < NPIX; ++px) out[ooff[px] + dofs] = val[px];
+                    // streaming stores: the output is written once and not read again; keeping it out of the L2's way is worth
+                    // 2-3 % ([measured] 512^3 0.251 -> 0.244 ms at 0 degrees, 0.294 -> 0.288 at 30; 1024^3 2.149 -> 2.102)
+                    for (int px = 0; px < NPIX; ++px) __builtin_nontemporal_store(val[px], &out[ooff[px] + dofs]);
                     stores_prev += NPIX;
                 } else if (exact_stores) {
 #pragma unroll
-                    for (int px = 0; px < NPIX; ++px) out[ooff[px] + dofs] = (in_yx[px] && z_ok) ? val[px] : 0.0f;
+                    for (int px = 0; px < NPIX; ++px) __builtin_nontemporal_store((in_yx[px] && z_ok) ? val[px] : 0.0f, &out[ooff[px] + dofs]);
                     stores_prev += NPIX;
                 } else {
 #pragma unroll
