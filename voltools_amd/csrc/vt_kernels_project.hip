@@ -43,7 +43,9 @@ __global__ __launch_bounds__(256) void plane_sum_kernel(const float* __restrict_
                 }
             }
             if constexpr (VEC == 4) {
-                const float4 v = *reinterpret_cast<const float4*>(p);
+                typedef float f4v __attribute__((ext_vector_type(4)));
+                const f4v vv = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p));         // read once: streaming load
+                const float4 v = make_float4(vv.x, vv.y, vv.z, vv.w);
                 acc[0] = fmaf(c, v.x, acc[0]); acc[1] = fmaf(c, v.y, acc[1]);
                 acc[2] = fmaf(c, v.z, acc[2]); acc[3] = fmaf(c, v.w, acc[3]);
             } else {
