@@ -33,6 +33,15 @@ def golden_volumes():
 
 
 @pytest.fixture(scope='session')
+def golden_m12():
+    """48x52x56 fixture: reference CPU path outputs for filt_bspline, pinned at margin 12 (make_golden.py)."""
+    g = np.load(os.path.join(GOLDEN, 'volumes_m12.npz'))
+    shape = tuple(int(s) for s in g['shape'])
+    vol = np.random.RandomState(int(g['seed'])).random_sample(shape).astype(np.float32)
+    return g, vol
+
+
+@pytest.fixture(scope='session')
 def golden_matrices():
     return np.load(os.path.join(GOLDEN, 'matrices.npz'))
 

@@ -8,6 +8,9 @@ What is recorded (inputs are re-creatable from the stored seeds/parameters; outp
   matrices.npz ....... outputs of the reference's voltools.utils matrix builders
                        (/root/reference/voltools/utils/matrices.py:22-154) for a parameter grid that
                        covers all 24 rotation orders, both units, centre on/off, partial kwargs.
+  volumes_m12.npz .... a seeded 48x52x56 float32 volume (large enough to have voxels 12 samples from every
+                       face) and the reference CPU path's filt_bspline outputs for three matrices: pins the
+                       prefiltered interpolations at the SURVEY 8c tolerance, 2e-6 at margin 12.
   volumes.npz ........ a seeded 20x24x28 float32 volume and the outputs of
                        voltools.affine / voltools.transform / StaticVolume(device='cpu')
                        (/root/reference/voltools/transforms.py:109-162, volume.py:93-101) for
@@ -117,6 +120,37 @@ def golden_volumes():
     print('volumes:', len(out), 'arrays,', os.path.getsize(os.path.join(HERE, 'volumes.npz')) // 1024, 'KiB')
 
 
+def golden_volumes_m12():
+    """48x52x56: the smallest comfortable volume with an interior 12 samples from every face (|z|^12 = 1.4e-7 of boundary
+    influence, the reference's own horizon, bspline.h:7), so filt_* is pinned at 2e-6 instead of 3e-5 at margin 8."""
+    shape = (48, 52, 56)
+    seed = 11
+    vol = np.random.RandomState(seed).random_sample(shape).astype(np.float32)
+    out = {'shape': np.array(shape), 'seed': np.array(seed)}
+    center = np.divide(np.subtract(shape, 1), 2, dtype=np.float32)
+    cases = {
+        'rot_inplane': dict(rotation=(0, 45, 0), rotation_order='rzxz'),
+        'rot_general': dict(rotation=(25.0, -40.0, 70.0), rotation_order='sxyz'),
+        'rot_scale_shift': dict(rotation=(10.0, 20.0, 30.0), rotation_order='rzxz', scale=(1.1, 0.9, 1.25),
+                                translation=(1.5, -2.0, 0.75)),
+    }
+    for name, kw in cases.items():
+        m = vt.utils.transform_matrix(center=center, **kw)
+        out[f'{name}/matrix'] = m
+        with redirect_stdout(io.StringIO()):
+            a = vt.affine(vol, m, interpolation='filt_bspline', device='cpu')
+            b = vt.affine(vol, m, interpolation='filt_bspline_simple', device='cpu')
+        assert np.array_equal(a, b)          # one scipy call serves both names on the CPU path (transforms.py:126-134)
+        out[f'{name}/filt_bspline'] = a
+    np.savez_compressed(os.path.join(HERE, 'volumes_m12.npz'), **out)
+    print('volumes_m12:', len(out), 'arrays,', os.path.getsize(os.path.join(HERE, 'volumes_m12.npz')) // 1024, 'KiB')
+
+
 if __name__ == '__main__':
-    golden_matrices()
-    golden_volumes()
+    which = sys.argv[1:] or ['matrices', 'volumes', 'volumes_m12']
+    if 'matrices' in which:
+        golden_matrices()
+    if 'volumes' in which:
+        golden_volumes()
+    if 'volumes_m12' in which:
+        golden_volumes_m12()

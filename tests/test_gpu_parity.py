@@ -187,6 +187,26 @@ def test_golden_reference_cpu_path_interior(interp, golden_volumes, golden_volum
         assert np.abs(got - ref)[mask].max() <= tol, (interp, case)
 
 
+@pytest.mark.parametrize('interp', ['filt_bspline', 'filt_bspline_simple'])
+def test_golden_reference_margin12(interp, golden_m12):
+    """The prefiltered interpolations against the reference's own CPU path at the tolerance SURVEY 8c states: 2e-6 where the
+    source coordinate is 12 samples away from every face (48x52x56 fixture), on every kernel family."""
+    g, vol = golden_m12
+    for case in ('rot_inplane', 'rot_general', 'rot_scale_shift'):
+        m = g[f'{case}/matrix']
+        ref = g[f'{case}/filt_bspline']
+        mask = interior_mask(m, ref.shape, vol.shape, 12)
+        assert mask.sum() > 10000
+        kernels = set()
+        for flags in (0, _native.FORCE_TILED, _native.FORCE_TILED | _native.NO_ZPAIR, _native.FORCE_TILED | _native.NO_MARCH,
+                      _native.FORCE_TILED | _native.NO_ZSEP | _native.FORCE_PACKED,
+                      _native.FORCE_TILED | _native.NO_ZSEP | _native.NO_PACKED, _native.FORCE_DIRECT):
+            got, info = run_case(vol, m, interp, flags)
+            kernels.add(info.last_kernel)
+            assert np.abs(got - ref)[mask].max() <= 2e-6, (interp, case, flags, info.last_kernel)
+        assert {1, 2, 6} <= kernels and (case != 'rot_inplane' or {3, 4, 5} <= kernels)
+
+
 @pytest.mark.parametrize('interp', ['linear', 'bspline'])
 def test_keep_outside_and_zero_fill(interp):
     """Outside voxels of a caller-supplied output: zero by default, untouched with keep_outside (the reference kernel's
@@ -506,10 +526,15 @@ def test_full_size_properties_512(interp):
     got = out.get()
     assert sv.info().last_kernel == (4 if interp == 'linear' else 5)
     d0 = 200
-    src = vol if interp == 'linear' else None
     if interp == 'linear':
         want = oracle.affine_ex(vol, np.asarray(m, np.float64), 'linear', (8, n, n), out_plane0=d0)
-        assert np.abs(got[d0:d0 + 8] - want).max() <= tol
+    else:
+        # the headline kernel (pair marching, round-aware chunks of 172 planes) against the oracle: prefilter a window of
+        # +-40 planes around the sub-block (|z|^38 = 2e-22 of the cut reaches the tapped planes), then sample it
+        w0, w1 = d0 - 40, d0 + 8 + 40
+        want = oracle.affine_ex(oracle.prefilter(vol[w0:w1]), np.asarray(m, np.float64), 'bspline', (8, n, n),
+                                plane0=w0, global_depth=n, out_plane0=d0)
+    assert np.abs(got[d0:d0 + 8] - want).max() <= tol
     # general rotation: tiled result equals the direct-gather result (two independent kernels)
     m = vt.utils.transform_matrix(rotation=(25, -40, 70), rotation_order='sxyz', center=centre((n, n, n)))
     sv.affine(m, output=out)

@@ -186,6 +186,16 @@ class DeviceArray:
         check(load().vt_memcpy_d2h(self.device, out.ctypes.data, self.ptr, self.nbytes), 'vt_memcpy_d2h')
         return out
 
+    def get_planes(self, d0: int, d1: int) -> np.ndarray:
+        """Planes [d0, d1) along axis 0 (a 1024^3 result is 4 GiB: tests and tools look at a few planes of it)."""
+        d0, d1 = int(d0), int(d1)
+        if not (0 <= d0 < d1 <= self.shape[0]):
+            raise ValueError(f'plane range [{d0}, {d1}) outside 0..{self.shape[0]}')
+        plane = int(np.prod(self.shape[1:])) * 4
+        out = np.empty((d1 - d0,) + self.shape[1:], dtype=np.float32)
+        check(load().vt_memcpy_d2h(self.device, out.ctypes.data, ctypes.c_void_p(self.ptr + d0 * plane), out.nbytes), 'vt_memcpy_d2h')
+        return out
+
     def set(self, a: np.ndarray) -> None:
         a = np.ascontiguousarray(a, dtype=np.float32)
         if a.shape != self.shape:
