@@ -182,7 +182,7 @@ def main():
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
     kind_code = {'linear': 0, 'bspline': 1, 'filt_bspline': 1}.get(interp, 2)
     kname = {1: f'vt::affine_direct<{kind_code}>', 2: f'vt::affine_tiled<{kind_code}', 3: f'vt::affine_tiled_zsep<{kind_code}',
-             4: f'vt::affine_march_zsep<{kind_code}', 5: f'vt::affine_march_zpair<{kind_code}'}.get(int(info.last_kernel), 'vt::affine')
+             4: f'vt::affine_march_zsep<{kind_code}', 5: f'vt::affine_march_zpair<{kind_code}', 8: f'vt::affine_march4<{kind_code}'}.get(int(info.last_kernel), 'vt::affine')
     traffic = measured_traffic('void ' + kname) if (n == 512 and world == 1) else None
     result = {
         'metric': 'Mvoxels/s, 512^3 f32 filt_bspline StaticVolume transform (resident source, device output)',

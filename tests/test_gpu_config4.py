@@ -47,7 +47,7 @@ def test_config4_1024_sweep_against_oracle_and_other_kernels(interp, big):
     t_out2 = torch.as_tensor(out2, device='cuda:0')
     sv = vt.StaticVolume(vol, interpolation=interp, device='gpu:0')
     tol = TOL[interp]
-    want_kernel = 4 if interp == 'linear' else 5
+    want_kernel = 8
     d0, nb, win = 500, 8, 40
     w0, w1 = d0 - win, d0 + nb + win
     window = vol[w0:w1].cpu().numpy()
@@ -65,7 +65,7 @@ def test_config4_1024_sweep_against_oracle_and_other_kernels(interp, big):
         err = float(np.abs(got - want).max())
         assert err <= tol, (interp, ang, err)
         # the other kernel families on the whole 1024^3 output (compared on the device)
-        for flags, k in ((_native.NO_ZPAIR, 4), (_native.NO_MARCH, 3)):
+        for flags, k in ((_native.NO_QUAD, 4 if interp == 'linear' else 5), (_native.NO_ZPAIR, 4), (_native.NO_MARCH, 3)):
             if interp == 'linear' and flags == _native.NO_ZPAIR:
                 continue
             sv.affine(m, output=out2, _flags=flags)
@@ -75,7 +75,7 @@ def test_config4_1024_sweep_against_oracle_and_other_kernels(interp, big):
             assert diff <= tol, (interp, ang, flags, diff)
     if interp == 'linear':
         sv.affine(np.eye(4, dtype=np.float32), output=out)
-        assert sv.info().last_kernel == 4
+        assert sv.info().last_kernel == 8
         sv.synchronize()
         assert bool(torch.equal(t_out, vol))
         sv.translate((7, -3, 11), output=out)

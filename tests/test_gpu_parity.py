@@ -76,6 +76,7 @@ def test_tiled_and_direct_match_oracle(interp, mname, shape):
     want = oracle.affine(vol, m, interp)
     kernels = set()
     for flags in (_native.FORCE_TILED | _native.FORCE_XSWAP, _native.FORCE_TILED | _native.FORCE_XSWAP | _native.NO_ZPAIR,
+                  _native.FORCE_TILED | _native.FORCE_XSWAP | _native.NO_QUAD, _native.FORCE_TILED | _native.NO_QUAD | _native.NO_RSWAP,
                   _native.FORCE_TILED, _native.FORCE_TILED | _native.NO_RSWAP, _native.FORCE_TILED | _native.NO_MARCH,
                   _native.FORCE_TILED | _native.NO_ZSEP | _native.FORCE_PACKED, _native.FORCE_TILED | _native.NO_ZSEP | _native.NO_PACKED,
                   _native.FORCE_DIRECT):
@@ -85,9 +86,9 @@ def test_tiled_and_direct_match_oracle(interp, mname, shape):
         assert err <= TOL[interp], f'{interp}/{mname}/{shape} flags={flags} kernel={info.last_kernel} err={err}'
     if mname in ('rot_axis1', 'rot_axis1_shift', 'rot_axis2', 'rot_axis2_shift'):
         # rotations about axis 1 / 2 march along an axis-exchanged resident copy
-        assert (4 in kernels) if interp == 'linear' else (5 in kernels and 4 in kernels)
+        assert 8 in kernels and ((4 in kernels) if interp == 'linear' else (5 in kernels and 4 in kernels))
     if mname in ('identity', 'shift_int', 'shift_frac', 'rot_inplane45', 'rot_inplane100', 'rot_inplane260'):
-        assert 3 in kernels and 4 in kernels         # both axis-0-separable kernels were exercised
+        assert 3 in kernels and 4 in kernels and 8 in kernels     # every axis-0-separable kernel was exercised
         assert (5 in kernels) == (interp != 'linear')   # cubic: the plane-pair marching kernel too
     if mname not in ('minify_big', 'far_outside'):
         assert 2 in kernels and 1 in kernels
@@ -105,7 +106,7 @@ def test_marching_staging_modes(interp, box, monkeypatch):
     for mname in ('shift_frac', 'rot_inplane45', 'rot_inplane100', 'rot_axis1_shift', 'rot_axis2_shift'):
         m = MATRICES[mname](shape)
         want = oracle.affine(vol, m, interp)
-        for flags in (_native.FORCE_TILED | _native.FORCE_XSWAP, _native.FORCE_TILED | _native.FORCE_XSWAP | _native.NO_ZPAIR):
+        for flags in (_native.FORCE_TILED | _native.FORCE_XSWAP | _native.NO_QUAD, _native.FORCE_TILED | _native.FORCE_XSWAP | _native.NO_ZPAIR):
             got, info = run_case(vol, m, interp, flags)
             assert info.last_kernel in (4, 5)
             assert np.abs(got - want).max() <= TOL[interp], (interp, box, mname, flags)
@@ -123,16 +124,18 @@ def test_marching_schedule_does_not_change_results(interp, knob, monkeypatch):
     vol = rand_vol(shape, 7)
     for mname in ('rot_inplane45', 'shift_frac'):
         m = MATRICES[mname](shape)
-        ref, info = run_case(vol, m, interp)
-        assert info.last_kernel in (4, 5)
-        for k, val in knob.items():
-            monkeypatch.setenv(k, val)
-        got, info2 = run_case(vol, m, interp)
-        for k in knob:
-            monkeypatch.delenv(k)
-        assert info2.last_kernel in (4, 5)
-        assert np.array_equal(got, ref), (interp, knob, mname, float(np.abs(got - ref).max()))
-        assert np.abs(ref - oracle.affine(vol, m, interp)).max() <= TOL[interp]
+        want = oracle.affine(vol, m, interp)
+        for flags, kernels in ((0, (8,)), (_native.NO_QUAD, (4, 5))):
+            ref, info = run_case(vol, m, interp, flags)
+            assert info.last_kernel in kernels
+            for k, val in knob.items():
+                monkeypatch.setenv(k, val)
+            got, info2 = run_case(vol, m, interp, flags)
+            for k in knob:
+                monkeypatch.delenv(k)
+            assert info2.last_kernel in kernels
+            assert np.array_equal(got, ref), (interp, knob, mname, flags, float(np.abs(got - ref).max()))
+            assert np.abs(ref - want).max() <= TOL[interp]
 
 
 @pytest.mark.parametrize('interp', ['linear', 'bspline', 'filt_bspline'])
@@ -149,8 +152,10 @@ def test_default_dispatch_uses_tiled_kernel_on_large_volumes(interp):
     assert np.abs(got - oracle.affine(vol, m, interp)).max() <= TOL[interp]
     m = MATRICES['rot_inplane45'](shape)
     got, info = run_case(vol, m, interp)
-    assert info.last_kernel == (4 if interp == 'linear' else 5)
+    assert info.last_kernel == 8
     assert np.abs(got - oracle.affine(vol, m, interp)).max() <= TOL[interp]
+    got, info = run_case(vol, m, interp, _native.NO_QUAD)
+    assert info.last_kernel == (4 if interp == 'linear' else 5)
     assert np.abs(got - oracle.affine(vol, m, interp)).max() <= TOL[interp]
 
 
@@ -161,7 +166,7 @@ def test_degenerate_and_ragged_shapes(shape, interp):
     for mname in ('identity', 'shift_frac', 'rot_general'):
         m = MATRICES[mname](shape)
         want = oracle.affine(vol, m, interp)
-        for flags in (_native.FORCE_TILED, _native.FORCE_TILED | _native.NO_ZPAIR, _native.FORCE_TILED | _native.NO_MARCH,
+        for flags in (_native.FORCE_TILED, _native.FORCE_TILED | _native.NO_QUAD, _native.FORCE_TILED | _native.NO_ZPAIR, _native.FORCE_TILED | _native.NO_MARCH,
                       _native.FORCE_TILED | _native.NO_ZSEP | _native.FORCE_PACKED, _native.FORCE_TILED | _native.NO_ZSEP | _native.NO_PACKED,
                       _native.FORCE_DIRECT):
             got, _ = run_case(vol, m, interp, flags)
@@ -198,13 +203,13 @@ def test_golden_reference_margin12(interp, golden_m12):
         mask = interior_mask(m, ref.shape, vol.shape, 12)
         assert mask.sum() > 10000
         kernels = set()
-        for flags in (0, _native.FORCE_TILED, _native.FORCE_TILED | _native.NO_ZPAIR, _native.FORCE_TILED | _native.NO_MARCH,
+        for flags in (0, _native.FORCE_TILED, _native.FORCE_TILED | _native.NO_QUAD, _native.FORCE_TILED | _native.NO_ZPAIR, _native.FORCE_TILED | _native.NO_MARCH,
                       _native.FORCE_TILED | _native.NO_ZSEP | _native.FORCE_PACKED,
                       _native.FORCE_TILED | _native.NO_ZSEP | _native.NO_PACKED, _native.FORCE_DIRECT):
             got, info = run_case(vol, m, interp, flags)
             kernels.add(info.last_kernel)
             assert np.abs(got - ref)[mask].max() <= 2e-6, (interp, case, flags, info.last_kernel)
-        assert {1, 2, 6} <= kernels and (case != 'rot_inplane' or {3, 4, 5} <= kernels)
+        assert {1, 2, 6} <= kernels and (case != 'rot_inplane' or {3, 4, 5, 8} <= kernels)
 
 
 @pytest.mark.parametrize('interp', ['linear', 'bspline'])
@@ -219,7 +224,8 @@ def test_keep_outside_and_zero_fill(interp):
         want_keep = oracle.affine(vol, m, interp, oracle.KEEP_OUTSIDE, output=stale.copy())
         want_zero = oracle.affine(vol, m, interp)
         assert (want_keep == 7.0).sum() > 100          # the case does have outside voxels
-        for flags in (_native.FORCE_TILED, _native.FORCE_TILED | _native.FORCE_XSWAP, _native.FORCE_DIRECT):
+        for flags in (_native.FORCE_TILED, _native.FORCE_TILED | _native.FORCE_XSWAP, _native.FORCE_TILED | _native.FORCE_XSWAP | _native.NO_QUAD,
+                      _native.FORCE_DIRECT):
             kept, _ = run_case(vol, m, interp, flags, keep=True, out_init=stale)
             zeroed, _ = run_case(vol, m, interp, flags, keep=False, out_init=stale)
             assert np.abs(kept - want_keep).max() <= 2e-6, (mname, flags)
@@ -469,7 +475,8 @@ def test_output_shape_other_than_source_shape(interp):
                          ('general', vt.utils.transform_matrix(rotation=(25, -40, 70), rotation_order='sxyz', scale=(1.2, 0.9, 1.1), center=c))):
             m32 = np.ascontiguousarray(m, dtype=np.float32)
             want = oracle.affine_ex(src, np.asarray(m32, np.float64), okind, out_shape)
-            for flags in (0, _native.FORCE_TILED | _native.FORCE_XSWAP, _native.FORCE_TILED | _native.NO_ZPAIR, _native.FORCE_TILED | _native.NO_ZSEP,
+            for flags in (0, _native.FORCE_TILED | _native.FORCE_XSWAP, _native.FORCE_TILED | _native.FORCE_XSWAP | _native.NO_QUAD,
+                          _native.FORCE_TILED | _native.NO_ZPAIR, _native.FORCE_TILED | _native.NO_ZSEP,
                           _native.FORCE_TILED | _native.NO_ZSEP | _native.FORCE_PACKED, _native.FORCE_DIRECT):
                 got = np.empty(out_shape, np.float32)
                 _native.check(lib.vt_volume_affine(h, m32.ctypes.data, got.ctypes.data, flags), 'affine')
@@ -508,7 +515,7 @@ def test_full_size_properties_512(interp):
     # identity: linear returns the input bit-for-bit; filt_bspline reproduces it in the interior
     sv.affine(np.eye(4, dtype=np.float32), output=out)
     got = out.get()
-    assert sv.info().last_kernel == (4 if interp == 'linear' else 5)
+    assert sv.info().last_kernel == 8
     if interp == 'linear':
         assert np.array_equal(got, vol)
     else:
@@ -524,7 +531,7 @@ def test_full_size_properties_512(interp):
     m = vt.utils.transform_matrix(rotation=(0, 45, 0), center=centre((n, n, n)))
     sv.affine(m, output=out)
     got = out.get()
-    assert sv.info().last_kernel == (4 if interp == 'linear' else 5)
+    assert sv.info().last_kernel == 8
     d0 = 200
     if interp == 'linear':
         want = oracle.affine_ex(vol, np.asarray(m, np.float64), 'linear', (8, n, n), out_plane0=d0)
@@ -551,7 +558,7 @@ def test_full_size_properties_512(interp):
         m = vt.utils.transform_matrix(rotation=rot, rotation_order='sxyz', translation=(0.25, 1.5, -2.0), center=centre((n, n, n)))
         sv.affine(m, output=out)
         a = out.get()
-        assert sv.info().last_kernel == (4 if interp == 'linear' else 5) or (rot[2] and interp == 'linear'), rot
+        assert sv.info().last_kernel == 8 or (rot[2] and interp == 'linear'), rot
         sv.affine(m, output=out, _flags=_native.NO_ZSEP)
         assert sv.info().last_kernel in (2, 6)
         assert np.abs(a - out.get()).max() <= tol, rot
@@ -561,7 +568,10 @@ def test_full_size_properties_512(interp):
     m = vt.utils.transform_matrix(rotation=(0, 33, 0), translation=(0.25, 1.5, -2.0), center=centre((n, n, n)))
     sv.affine(m, output=out)
     a = out.get()
+    assert sv.info().last_kernel == 8
+    sv.affine(m, output=out, _flags=_native.NO_QUAD)
     assert sv.info().last_kernel == (4 if interp == 'linear' else 5)
+    assert np.abs(a - out.get()).max() <= tol
     sv.affine(m, output=out, _flags=_native.NO_ZPAIR)
     assert sv.info().last_kernel == 4
     assert np.abs(a - out.get()).max() <= tol
@@ -598,7 +608,7 @@ def test_slab_handles_reproduce_whole_volume(interp):
     for m in mats:
         want = oracle.affine(vol, m, interp)
         projs = {}
-        for flags in (0, _native.NO_ZPAIR, _native.NO_MARCH, _native.NO_ZSEP, _native.FORCE_DIRECT):
+        for flags in (0, _native.NO_QUAD, _native.NO_ZPAIR, _native.NO_MARCH, _native.NO_ZSEP, _native.FORCE_DIRECT):
             parts = []
             for r, (g0, g1) in enumerate(slab_bounds(counts)):
                 (w0, w1), _, _ = plan_halo_exchange(counts, r, halo)

@@ -260,6 +260,7 @@ int init_device(int dev)
     if (dev < 64) {
         std::call_once(g_init_flag[dev], [dev]() {
             g_init_err[dev] = init_affine_kernels();
+            if (g_init_err[dev] == hipSuccess) g_init_err[dev] = init_quad_kernels();
             hipDeviceProp_t prop;
             if (g_init_err[dev] == hipSuccess) g_init_err[dev] = hipGetDeviceProperties(&prop, dev);
             if (g_init_err[dev] == hipSuccess) {
@@ -289,6 +290,7 @@ struct Tuning {
     bool exp_nostore = false;      // VT_EXP_NOSTORE / VT_EXP_NOLOAD / VT_EXP_NOLDS: ablation builds (-DVT_EXPERIMENTS) only
     bool exp_noload = false;
     bool exp_nolds = false;
+    bool exp_noloop = false;
     void read()
     {
         auto num = [](const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; };
@@ -305,6 +307,7 @@ struct Tuning {
         exp_nostore = std::getenv("VT_EXP_NOSTORE") != nullptr;
         exp_noload = std::getenv("VT_EXP_NOLOAD") != nullptr;
         exp_nolds = std::getenv("VT_EXP_NOLDS") != nullptr;
+        exp_noloop = std::getenv("VT_EXP_NOLOOP") != nullptr;
     }
 };
 
@@ -370,6 +373,11 @@ struct vt_volume {
     int Px = 0;
     float* d_tmp_x = nullptr;          // exchanged result of an axis-2 launch, before it is turned back
     size_t tmp_x_elems = 0;
+    float* d_src_q = nullptr;          // plane-quad copies ([z/4][y][x][4]; vt_kernels_quad.hip) of the four orientations; lazy
+    float* d_src_t_q = nullptr;
+    float* d_src_r_q = nullptr;
+    float* d_src_x_q = nullptr;
+    size_t quad_bytes[4] = {0, 0, 0, 0};   // allocation sizes of the four quad copies (vt_volume_info)
     int P2 = 0;                        // floats per pair-row of d_src_zp
     float* d_scratch_out = nullptr;    // staging for host outputs
     double* d_batch_m = nullptr;       // batch launches: n x 12 folded matrices
@@ -493,6 +501,125 @@ int estimate_packed_vectors(const double m[12], int th, int tw, int halo, int ro
     return worst + worst / 64 + 2;
 }
 
+// Upper estimate of the packed footprint of a TH x TW in-plane tile in POSITIONS (plane-quad layout: one 16-byte vector per
+// position, no alignment), as affine_march4 packs it.  A 3 x 3 grid of sub-voxel offsets is sampled; a row's span changes by
+// at most one position with the offset, hence the margin of one position per row.  A tile that still exceeds the slot
+// takes the kernel's direct-gather path (slow, never wrong).
+int estimate_span_positions(const double m[12], int th, int tw, int halo, int rows_cap, int* rows_out)
+{
+    const double a1 = m[5], b1 = m[6], a2 = m[9], b2 = m[10];
+    const double ia1 = march_recip(a1), ib1 = march_recip(b1);
+    double neg1 = 0, neg2 = 0;
+    for (double e : {a1 * (th - 1), b1 * (tw - 1)}) if (e < 0) neg1 += e;
+    for (double e : {a2 * (th - 1), b2 * (tw - 1)}) if (e < 0) neg2 += e;
+    int worst = 0, worst_rows = 0;
+    for (int oy = 0; oy < 3; ++oy)
+        for (int ox = 0; ox < 3; ++ox) {
+            const double by = 0.33 * oy + 0.013 - neg1 + halo, bx = 0.33 * ox + 0.017 - neg2 + halo;
+            int total = 0, rows = 0;
+            for (int Y = 0; Y < rows_cap; ++Y) {
+                int mn, mx;
+                if (!march_row_span(a1, b1, a2, b2, ia1, ib1, by, bx, Y, th, tw, halo, &mn, &mx)) continue;
+                total += mx - mn + 1;
+                rows = Y + 1;
+            }
+            worst = std::max(worst, total);
+            worst_rows = std::max(worst_rows, rows);
+        }
+    *rows_out = worst_rows + 1;
+    return worst + worst_rows + 8;
+}
+
+// Marching kernel on the plane-quad layout (kind 8; vt_kernels_quad.hip) for an axis-0-separable matrix.  Returns false when
+// no configuration fits (the caller goes on to the plain / plane-pair marching kernels).
+bool plan_quad(vt_volume* v, const double m[12], int flags, AffineParams* p, TilePlan* plan)
+{
+    const bool cubic = is_cubic(v->interp);
+    const int halo = cubic ? 1 : 0, halo2 = 2 * halo;
+    const int Wq = (v->W + 1 + 7) & ~7;                    // positions per quad-row: >= one zero position, rows of whole 128-byte lines
+    const int64_t quad_bytes = (int64_t)v->H * Wq * 16;
+    if (quad_bytes >= 0x7fffffffLL) return false;
+    // output addressing of the kernel: 31-bit byte offsets inside a tile (rows) and inside a chunk (planes), for either
+    // orientation of the output strides (axis-exchanged launches swap them afterwards)
+    const int64_t max_stride = (int64_t)std::max(v->oD, v->oH) * v->oW;
+    for (int c = 0; c < quad_config_count(); ++c) {
+        if (v->tune.tile >= 0 && c != v->tune.tile) continue;
+        int th, tw, nt;
+        quad_config(c, &th, &tw, &nt);
+        if ((int64_t)th * max_stride * 4 >= 0x7fffffffLL) continue;
+        const int T[3] = {1, th, tw};
+        int L[3] = {0, 0, 0};
+        bool ok = true;
+        for (int r = 1; r < 3 && ok; ++r) {
+            double ext = 0;
+            for (int k = 1; k < 3; ++k) ext += std::fabs(m[4 * r + k]) * (T[k] - 1);
+            if (!(ext < 4096.0)) { ok = false; break; }
+            L[r] = (int)std::floor(ext) + 3 + halo2;
+        }
+        if (!ok || L[1] > march_rows_max()) continue;
+        int rows = 0;
+        const int npos = estimate_span_positions(m, th, tw, halo, L[1] + 1, &rows);
+        if (rows > march_rows_max()) continue;
+        const int nvec64 = (npos + 63) & ~63;
+        if (nvec64 > nt * march_max_it()) continue;
+        const int slot_bytes = nvec64 * 16;                   // a power-of-two-free size is fine: the ring toggles with XOR of slot_bytes...
+        // ... which needs slot 0 at offset 0 and slot 1 at offset slot_bytes: any size works
+        const int64_t bytes = std::max<int64_t>(2LL * slot_bytes, march_table_bytes());
+        if (bytes > v->lds_limit) continue;
+        plan->kind = 8; plan->cfg = c; plan->td = 4; plan->th = th; plan->tw = tw;
+        plan->lds_bytes = (int)bytes;
+        p->Lz = 2; p->Ly = std::min(L[1], march_rows_max()); p->Lx = npos; p->Lx_used = npos;
+        p->slot_floats = slot_bytes / 4;
+        break;                                    // configurations are listed in order of preference: first fit wins
+    }
+    if (plan->kind != 8) return false;
+    const int T[3] = {1, plan->th, plan->tw};
+    for (int r = 0; r < 3; ++r) {
+        double neg = 0, pos = 0;
+        for (int k = 1; k < 3; ++k) {
+            const double e = m[4 * r + k] * (T[k] - 1);
+            if (e < 0) neg += e; else pos += e;
+        }
+        p->neg[r] = neg; p->pos[r] = pos;
+    }
+    const double fl = std::floor(m[3]);
+    p->zoff = (int32_t)fl;
+    p->fz = (float)(m[3] - fl);
+    p->nTh = (v->oH + plan->th - 1) / plan->th;
+    p->nTw = (v->oW + plan->tw - 1) / plan->tw;
+    p->sPq = 4 * Wq;
+    p->zero_off_q = v->W * 16;
+    p->flags = (flags & VT_KEEP_OUTSIDE) | (v->tune.exp_nostore ? (1 << 21) : 0) | (v->tune.exp_noload ? (1 << 22) : 0) |
+               (v->tune.exp_nolds ? (1 << 26) : 0) | (v->tune.exp_noloop ? (1 << 27) : 0);
+    const int64_t inplane = (int64_t)p->nTh * p->nTw;
+    // chunk depth: every chunk pays one or two quad steps beyond its own planes (history of the first outputs, misaligned
+    // ends), so chunks are deeper than the plain kernels' -- 64 planes = 16 steps + ~1.5
+    int target_dch = 64;
+    if (v->tune.dch > 0) target_dch = std::max(4, v->tune.dch);
+    int64_t nchunks = std::max<int64_t>(1, (v->oD + target_dch - 1) / target_dch);
+    // small volumes: shorter chunks until the launch has ~4 workgroups per CU, not below 8 planes per chunk
+    if (v->tune.dch <= 0)
+        nchunks = std::max(nchunks, std::min<int64_t>((4 * (int64_t)v->cu_count + inplane - 1) / inplane, (v->oD + 7) / 8));
+    // scalar byte offsets: source quads of a chunk from its first quad, output planes from its first plane (31 bits each)
+    const int64_t n_addr = std::max(((int64_t)(v->oD / 4 + 4) * quad_bytes) / 0x60000000LL + 1, ((int64_t)v->oD * max_stride * 4) / 0x60000000LL + 1);
+    nchunks = std::max<int64_t>(nchunks, n_addr);
+    const int bpc = quad_blocks_per_cu(plan->cfg, v->interp, plan->lds_bytes);
+    plan->blocks_per_cu = bpc;
+    if (v->tune.dch <= 0)
+        nchunks = round_aware_chunks(v->oD, 4, inplane, (int64_t)v->cu_count * bpc, nchunks, 2 + halo2, 8, n_addr);
+    int dch = (int)((v->oD + nchunks - 1) / nchunks);
+    dch = (dch + 3) & ~3;
+    nchunks = (v->oD + dch - 1) / dch;
+    if ((int64_t)dch * max_stride * 4 >= 0x7fffffffLL) { plan->kind = 1; return false; }
+    p->dch = dch;
+    p->nTd = (int)nchunks;
+    if (v->tune.blk_h > 0 && v->tune.blk_w > 0) { p->blk_h = v->tune.blk_h; p->blk_w = v->tune.blk_w; }
+    const int64_t grid = inplane * nchunks;
+    if (grid > 0x7fffffffLL) { plan->kind = 1; return false; }
+    plan->grid = (int)grid;
+    return true;
+}
+
 // Choose the kernel and tile shape for one matrix (host side, a few hundred flops).
 int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, TilePlan* plan)
 {
@@ -531,6 +658,7 @@ int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, Ti
     const bool zsep = !(flags & VT_NO_ZSEP) && m[0] == 1.0 && m[1] == 0.0 && m[2] == 0.0 && m[4] == 0.0 && m[8] == 0.0 &&
                       std::fabs(m[3]) < 1.0e9;
     p->zero_off = ((v->W + 3) & ~3) * 4;
+    if (zsep && !(flags & (VT_NO_MARCH | VT_NO_QUAD | VT_NO_ZPAIR)) && plan_quad(v, m, flags, p, plan)) return 0;
     if (zsep && !(flags & VT_NO_MARCH) && (int64_t)v->H * v->P * 4 < 0x7fffffffLL) {
         // marching kernel: pick the in-plane tile with the least staged bytes per pixel
         const double fl = std::floor(m[3]);
@@ -928,6 +1056,8 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
     // the output addressing changes (plane stride oW, row stride oH*oW).  Whole-volume handles only (no slab offsets).
     const float* src_plain = v->d_src;
     float** pair_slot = &v->d_src_zp;
+    float** quad_slot = &v->d_src_q;
+    int quad_idx = 0;
     int srcD = v->D, srcH = v->H;
     const size_t n_out = (size_t)v->oD * v->oH * v->oW;
     const bool ysep = !(flags & (VT_NO_ZSEP | VT_NO_MARCH | VT_FORCE_DIRECT)) && m[5] == 1.0 && m[4] == 0.0 && m[6] == 0.0 &&
@@ -953,7 +1083,7 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
         TilePlan plans;
         rc = plan_launch(&sw, ms, flags, &ps, &plans);
         if (rc) return rc;
-        if ((plans.kind == 4 || plans.kind == 5) && !v->d_src_t) {
+        if ((plans.kind == 4 || plans.kind == 5 || plans.kind == 8) && !v->d_src_t) {
             const size_t bytes = (size_t)v->D * v->H * v->P * sizeof(float);
             if (hipMalloc(reinterpret_cast<void**>(&v->d_src_t), bytes) != hipSuccess) {
                 (void)hipGetLastError();          // no room for a second copy: the general kernels serve this matrix
@@ -963,7 +1093,8 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
                 VT_HIP(launch_relayout_swap01(v->d_src, v->d_src_t, v->D, v->H, v->P, v->stream));
             }
         }
-        if (plans.kind == 4 || plans.kind == 5) {
+        if (plans.kind == 4 || plans.kind == 5 || plans.kind == 8) {
+            quad_slot = &v->d_src_t_q; quad_idx = 1;
             p = ps; plan = plans;
             p.ostride = v->oW; p.orow = (int64_t)v->oH * v->oW;
             p.ord[0] = 1; p.ord[1] = 0; p.ord[2] = 2;          // original (d, h, w) = this launch's columns (1, 0, 2)
@@ -1001,7 +1132,7 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
         TilePlan plans;
         rc = plan_launch(&sw, ms, flags, &ps, &plans);
         if (rc) return rc;
-        if ((plans.kind == 4 || plans.kind == 5) && v->tmp_x_elems < n_out) {
+        if ((plans.kind == 4 || plans.kind == 5 || plans.kind == 8) && v->tmp_x_elems < n_out) {
             if (v->d_tmp_x) { VT_HIP(hipFree(v->d_tmp_x)); v->d_tmp_x = nullptr; v->tmp_x_elems = 0; }
             if (hipMalloc(reinterpret_cast<void**>(&v->d_tmp_x), n_out * sizeof(float)) != hipSuccess) {
                 (void)hipGetLastError();          // no room: the general kernels serve this matrix
@@ -1009,7 +1140,7 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
                 plans.kind = 0;
             } else v->tmp_x_elems = n_out;
         }
-        if ((plans.kind == 4 || plans.kind == 5) && !v->d_src_x) {
+        if ((plans.kind == 4 || plans.kind == 5 || plans.kind == 8) && !v->d_src_x) {
             v->Px = sw.P;
             const size_t bytes = (size_t)v->W * v->H * v->Px * sizeof(float);
             if (hipMalloc(reinterpret_cast<void**>(&v->d_src_x), bytes) != hipSuccess) {
@@ -1022,7 +1153,8 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
                                           (int64_t)v->H * v->Px, v->Px, v->stream));
             }
         }
-        if (plans.kind == 4 || plans.kind == 5) {
+        if (plans.kind == 4 || plans.kind == 5 || plans.kind == 8) {
+            quad_slot = &v->d_src_x_q; quad_idx = 3;
             p = ps; plan = plans;
             src_plain = v->d_src_x; pair_slot = &v->d_src_x_zp;
             srcD = v->W; srcH = v->H; pair_W = v->D; pair_P = v->Px;
@@ -1052,7 +1184,7 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
         TilePlan plans;
         rc = plan_launch(&sw, ms, flags, &ps, &plans);
         if (rc) return rc;
-        if ((plans.kind == 4 || plans.kind == 5) && !v->d_src_r) {
+        if ((plans.kind == 4 || plans.kind == 5 || plans.kind == 8) && !v->d_src_r) {
             v->Pr = sw.P;
             const size_t bytes = (size_t)v->D * v->W * v->Pr * sizeof(float);
             if (hipMalloc(reinterpret_cast<void**>(&v->d_src_r), bytes) != hipSuccess) {
@@ -1066,7 +1198,8 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
                                           v->Pr, (int64_t)v->W * v->Pr, v->stream));
             }
         }
-        if (plans.kind == 4 || plans.kind == 5) {
+        if (plans.kind == 4 || plans.kind == 5 || plans.kind == 8) {
+            quad_slot = &v->d_src_r_q; quad_idx = 2;
             p = ps; plan = plans;
             src_plain = v->d_src_r; pair_slot = &v->d_src_r_zp;
             srcD = v->D; srcH = v->W; pair_W = v->H; pair_P = v->Pr;
@@ -1093,7 +1226,21 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
     float* const d_final = d_out;
     if (xswap) d_out = v->d_tmp_x;                // the kernels write the exchanged result [w][h][d]
 
-    if (plan.kind == 5) {
+    if (plan.kind == 8) {
+        if (!*quad_slot) {
+            // build the plane-quad copy of the (prefiltered) resident source once; positions beyond the row's width stay zero
+            const size_t qbytes = (size_t)((srcD + 3) / 4) * srcH * p.sPq * sizeof(float);
+            VT_HIP(hipMalloc(reinterpret_cast<void**>(quad_slot), qbytes));
+            v->quad_bytes[quad_idx] = qbytes;
+            VT_HIP(hipMemsetAsync(*quad_slot, 0, qbytes, v->stream));
+            VT_HIP(launch_relayout_zquad(src_plain, *quad_slot, srcD, srcH, pair_W, pair_P, p.sPq, v->stream));
+        }
+        VT_HIP(launch_affine_quad(plan.cfg, v->interp, *quad_slot, d_out, p, plan.grid, plan.lds_bytes, v->stream));
+        v->last_kernel = 8;
+        v->last_tile[0] = plan.td; v->last_tile[1] = plan.th; v->last_tile[2] = plan.tw;
+        v->last_lds[0] = p.Lz; v->last_lds[1] = p.Ly; v->last_lds[2] = p.Lx;
+        v->last_lds_bytes = plan.lds_bytes; v->last_grid = plan.grid;
+    } else if (plan.kind == 5) {
         if (!*pair_slot) {
             // build the plane-pair copy of the (prefiltered) resident source once
             v->P2 = p.sP2;
@@ -1344,7 +1491,7 @@ int oneshot_pipelined(int dev, const float* h_volume, int D, int H, int W, int i
     }
     const double t_uploads = now_ms();
     const int halo = is_cubic(interp) ? 2 : 1;
-    const int lflags = (flags | VT_OUT_DEVICE | VT_NO_ZPAIR | VT_NO_RSWAP) & ~VT_KEEP_OUTSIDE;
+    const int lflags = (flags | VT_OUT_DEVICE | VT_NO_ZPAIR | VT_NO_QUAD | VT_NO_RSWAP) & ~VT_KEEP_OUTSIDE;
     // Kernel stream, per uploaded chunk: (filt_*) X and Y passes of the prefilter on the chunk's planes (plane-local), then
     // every axis-0 chunk of the prefilter whose input planes (its own + warm-up) are there, then every output slab whose
     // source planes are final.  The prefilter runs the same kernels on the same chunk grid as for a resident volume.
@@ -1746,6 +1893,10 @@ int vt_volume_destroy(vt_volume_t* v)
     if (v->d_src_r) hipFree(v->d_src_r);
     if (v->d_src_r_zp) hipFree(v->d_src_r_zp);
     if (v->d_src_x_zp) hipFree(v->d_src_x_zp);
+    if (v->d_src_q) hipFree(v->d_src_q);
+    if (v->d_src_t_q) hipFree(v->d_src_t_q);
+    if (v->d_src_r_q) hipFree(v->d_src_r_q);
+    if (v->d_src_x_q) hipFree(v->d_src_x_q);
     if (v->d_tmp_x) hipFree(v->d_tmp_x);
     if (v->d_scratch_out) cached_free(v->dev, v->d_scratch_out, v->scratch_elems * sizeof(float));
     if (v->d_proj_tmp) hipFree(v->d_proj_tmp);
@@ -1772,7 +1923,8 @@ int vt_volume_info(const vt_volume_t* v, vt_volume_info_t* info)
     info->resident_bytes = plain + (v->d_src_zp ? (uint64_t)((v->D + 1) / 2) * v->H * v->P2 * sizeof(float) : 0) +
                            (v->d_src_t ? plain : 0) +
                            (v->d_src_t_zp ? (uint64_t)((v->H + 1) / 2) * v->D * v->P2 * sizeof(float) : 0) +
-                           (v->proj ? (uint64_t)3 * v->proj->H * v->proj->P * sizeof(float) : 0);
+                           (v->proj ? (uint64_t)3 * v->proj->H * v->proj->P * sizeof(float) : 0) +
+                           v->quad_bytes[0] + v->quad_bytes[1] + v->quad_bytes[2] + v->quad_bytes[3];
     return 0;
 }
 

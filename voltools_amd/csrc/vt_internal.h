@@ -42,6 +42,8 @@ struct AffineParams {
                                // so that the chain is the original problem's and boundary voxels classify as in affine_direct)
     int64_t ostride, orow;     // marching kernels: element stride between output planes / rows (oH*oW, oW unless axes are swapped)
     int blk_h, blk_w;          // marching kernels: blocked tile order inside a chunk layer (tiles per block; 0 = plain order)
+    int32_t sPq;               // plane-quad layout: floats per quad-row (4 * positions per row)
+    int32_t zero_off_q;        // plane-quad layout: byte offset of a zero vector inside any quad-plane
 };
 
 
@@ -112,7 +114,8 @@ struct PackGeom {
 };
 
 struct TilePlan {
-    int kind;            // 1 direct, 2 tiled, 3 tiled axis-0-separable, 4 marching, 5 marching on plane pairs, 6 tiled with packed footprints
+    int kind;            // 1 direct, 2 tiled, 3 tiled axis-0-separable, 4 marching, 5 marching on plane pairs, 6 tiled with packed footprints,
+                         // 8 marching on plane quads
     int cfg;             // index into the tile table
     int td, th, tw;
     int lds_bytes;
@@ -197,6 +200,14 @@ hipError_t launch_relayout_zpair(const float* src, float* dst, int D, int H, int
 hipError_t launch_transpose02(const float* src, float* dst, int n0, int n1, int n2, int64_t ss0, int64_t ss1,
                               int64_t ds0, int64_t ds1, hipStream_t stream);
 hipError_t launch_relayout_swap01(const float* src, float* dst, int D, int H, int P, hipStream_t stream);
+// plane-quad marching kernel (vt_kernels_quad.hip)
+int quad_config_count();
+void quad_config(int idx, int* th, int* tw, int* nt);
+int quad_blocks_per_cu(int cfg, int interp, int lds_bytes);
+hipError_t init_quad_kernels();
+hipError_t launch_relayout_zquad(const float* src, float* dst, int D, int H, int W, int P, int Pq, hipStream_t stream);
+hipError_t launch_affine_quad(int cfg, int interp, const float* srcq, float* out, const AffineParams& p,
+                              int grid, int lds_bytes, hipStream_t stream);
 int packed_config_count();
 void packed_config(int idx, int* td, int* th, int* tw);
 int packed_rows_max();
