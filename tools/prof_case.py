@@ -24,7 +24,12 @@ ap.add_argument('--flags', type=int, default=0)
 args = ap.parse_args()
 
 n = args.size
-vol = np.random.RandomState(0).random_sample((n, n, n)).astype(np.float32)
+if n >= 768:                                   # 4 GiB of host random numbers per process is most of a short run: generate on the device
+    import torch
+    g = torch.Generator(device='cuda:0'); g.manual_seed(0)
+    vol = torch.rand((n, n, n), dtype=torch.float32, device='cuda:0', generator=g)
+else:
+    vol = np.random.RandomState(0).random_sample((n, n, n)).astype(np.float32)
 sv = vt.StaticVolume(vol, interpolation=args.interp, device='gpu:0')
 out = vt.empty((n, n, n), device='gpu:0')
 c = np.divide(np.subtract((n, n, n), 1), 2, dtype=np.float32)

@@ -225,13 +225,14 @@ class _HostResultPool:
     Writing 512 MiB into fresh pages costs ~45 ms of page faults on the GPU box -- 5x the PCIe transfer itself
     (tools/pcie_probe.py).  Results therefore come from a small pool of host buffers that stay faulted-in and
     registered with the HIP runtime: a buffer is handed out again once the caller has dropped every array that
-    views it (reference count of the owner back at the pool's own).  Arrays the caller keeps are never reused.
+    views it (reference count of the backing array back at the pool's own).  Arrays the caller keeps are never reused.
+    Every pooled buffer is page-aligned and owns whole pages (``_page_aligned_floats``).
     ``VT_HOST_POOL=0`` disables the pool; ``VT_HOST_POOL_MB`` caps it (default: a tenth of the machine's memory, between
     4 and 64 GiB -- a loop over 1024^3 one-shot results alternates between two 4-GiB buffers: 94 ms per call with both in the
     pool, 250 ms when one of them is a fresh allocation every time)."""
 
     def __init__(self):
-        self.entries = []          # owner arrays (1-D float32), most recently used last
+        self.entries = []          # (backing uint8 array, offset of the first page boundary, floats, registered bytes); most recently used last
         self.enabled = os.environ.get('VT_HOST_POOL', '1') != '0'
         try:
             phys_mb = (os.sysconf('SC_PAGE_SIZE') * os.sysconf('SC_PHYS_PAGES')) >> 20
@@ -240,21 +241,35 @@ class _HostResultPool:
         default_mb = min(65536, max(4096, phys_mb // 10))
         self.cap = int(os.environ.get('VT_HOST_POOL_MB', str(default_mb))) << 20
         self.min_bytes = 1 << 20   # small results are not worth a pool slot
-        # reference count of an owner that nobody outside the pool refers to, measured by the scan itself
-        self._idle = self._scan([np.empty(1, dtype=np.float32)], 1, calibrate=True)
+        # reference count of a backing array that nobody outside the pool refers to, measured by the scan itself
+        # (the entry is built inside the call: a local name for the backing array would count as a holder)
+        self._idle = self._scan([self._new_entry(1)], 1, calibrate=True)
 
     def _scan(self, entries, n, calibrate=False) -> int:
-        """Index of a free buffer of n floats (most recently used first), or -1."""
+        """Index of a free buffer of n floats (most recently used first), or -1.  Every array handed out is a view whose
+        base is the backing array (numpy collapses view chains), so its reference count tells whether a caller still holds one."""
         import sys
         for i in range(len(entries) - 1, -1, -1):
-            e = entries[i]
-            if e.size == n:
-                c = sys.getrefcount(e)
+            if entries[i][2] == n:
+                c = sys.getrefcount(entries[i][0])
                 if calibrate:
                     return c
                 if c <= self._idle:
                     return i
         return -1
+
+    @staticmethod
+    def _new_entry(n: int):
+        return _page_aligned_backing(n)[:2] + (n, (n * 4 + _PAGE - 1) // _PAGE * _PAGE)
+
+    @staticmethod
+    def _view(entry, shape) -> np.ndarray:
+        raw, off, n, _ = entry
+        return raw[off:off + 4 * n].view(np.float32).reshape(shape)
+
+    @staticmethod
+    def _addr(entry) -> int:
+        return entry[0].ctypes.data + entry[1]
 
     def take(self, shape, device: int) -> np.ndarray:
         n = int(np.prod(shape))
@@ -263,12 +278,12 @@ class _HostResultPool:
         i = self._scan(self.entries, n)
         if i >= 0:
             self.entries.append(self.entries.pop(i))
-            return self.entries[-1].reshape(shape)
+            return self._view(self.entries[-1], shape)
         # make room: drop free buffers of other sizes, oldest first
-        total = sum(x.nbytes for x in self.entries) + n * 4
+        total = sum(e[3] for e in self.entries) + n * 4
         while total > self.cap:
             j = -1
-            for size in sorted({x.size for x in self.entries}):
+            for size in sorted({e[2] for e in self.entries}):
                 j = self._scan(self.entries[::-1], size)        # reversed: oldest first
                 if j >= 0:
                     j = len(self.entries) - 1 - j
@@ -276,18 +291,35 @@ class _HostResultPool:
             if j < 0:
                 break
             victim = self.entries.pop(j)
-            load().vt_host_unregister(device, ctypes.c_void_p(victim.ctypes.data))
-            total -= victim.nbytes
+            load().vt_host_unregister(device, ctypes.c_void_p(self._addr(victim)))
+            total -= victim[3]
             del victim
-        owner = np.empty(n, dtype=np.float32)
-        if total <= self.cap and load().vt_host_register(device, ctypes.c_void_p(owner.ctypes.data), owner.nbytes) == 0:
-            self.entries.append(owner)
-        return owner.reshape(shape)
+        entry = self._new_entry(n)
+        if total <= self.cap and load().vt_host_register(device, ctypes.c_void_p(self._addr(entry)), entry[3]) == 0:
+            self.entries.append(entry)
+        return self._view(entry, shape)
 
     def clear(self, device: int = 0) -> None:
         for e in self.entries:
-            load().vt_host_unregister(device, ctypes.c_void_p(e.ctypes.data))
+            load().vt_host_unregister(device, ctypes.c_void_p(self._addr(e)))
         self.entries = []
+
+
+_PAGE = 4096
+
+
+def _page_aligned_backing(n: int):
+    """Backing store for a float32 result of n elements that starts on a page boundary and owns every page it touches:
+    (uint8 array, offset of the first page boundary in it, bytes to register -- a whole number of pages).
+    Registration pins and maps WHOLE pages at the host's own virtual address; a heap array shares its first and last page
+    with its neighbours, so registering it as it stands overlaps whatever else gets pinned on those pages (another pooled
+    buffer, a caller's array during a copy, the runtime's own temporary pin of a pageable transfer) -- and releasing any one
+    of them takes the shared page out of the GPU's page table under the others: a `Memory access fault by GPU` on a
+    page-aligned HOST address at some later copy (the round-1 abort inside vt_volume_create; seen again in round 2 with the
+    runtime's message intact)."""
+    reg = (n * 4 + _PAGE - 1) // _PAGE * _PAGE
+    raw = np.empty(reg + _PAGE, dtype=np.uint8)
+    return raw, (-raw.ctypes.data) % _PAGE, reg
 
 
 _host_pool = _HostResultPool()

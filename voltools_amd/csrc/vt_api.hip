@@ -291,6 +291,7 @@ struct Tuning {
     bool exp_noload = false;
     bool exp_nolds = false;
     bool exp_noloop = false;
+    int quad_nt = -1;              // VT_QUAD_NT: 1 / 0 = nontemporal / plain output stores of the plane-quad kernel, -1 = planner's choice
     void read()
     {
         auto num = [](const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; };
@@ -308,6 +309,7 @@ struct Tuning {
         exp_noload = std::getenv("VT_EXP_NOLOAD") != nullptr;
         exp_nolds = std::getenv("VT_EXP_NOLDS") != nullptr;
         exp_noloop = std::getenv("VT_EXP_NOLOOP") != nullptr;
+        quad_nt = num("VT_QUAD_NT", -1);
     }
 };
 
@@ -409,9 +411,17 @@ struct PinnedScope {
     PinnedScope(const void* p, size_t bytes)
     {
         static const bool off = std::getenv("VT_NO_PIN") != nullptr;
-        if (!off && bytes >= (8u << 20)) {
-            ptr = const_cast<void*>(p);
-            pinned = hipHostRegister(ptr, bytes, hipHostRegisterDefault) == hipSuccess;
+        if (!off && p && bytes >= (8u << 20)) {
+            // Whole pages only: registration pins and maps pages, and a range that starts or ends inside a page shares that
+            // page with whatever else is registered on it (the Python layer's pooled result buffers, the runtime's own
+            // temporary pins); unregistering one of the overlapping ranges unmaps the shared page under the others -> a GPU
+            // memory access fault on a host address at some later copy.  The first and the last page of
+            // the caller's array are mapped memory of this process, so rounding outward is safe.
+            constexpr uintptr_t kPage = 4096;
+            const uintptr_t a0 = reinterpret_cast<uintptr_t>(p) & ~(kPage - 1);
+            const uintptr_t a1 = (reinterpret_cast<uintptr_t>(p) + bytes + kPage - 1) & ~(kPage - 1);
+            ptr = reinterpret_cast<void*>(a0);
+            pinned = hipHostRegister(ptr, a1 - a0, hipHostRegisterDefault) == hipSuccess;
             if (!pinned) (void)hipGetLastError();
         }
     }
@@ -591,10 +601,16 @@ bool plan_quad(vt_volume* v, const double m[12], int flags, AffineParams* p, Til
     p->zero_off_q = v->W * 16;
     p->flags = (flags & VT_KEEP_OUTSIDE) | (v->tune.exp_nostore ? (1 << 21) : 0) | (v->tune.exp_noload ? (1 << 22) : 0) |
                (v->tune.exp_nolds ? (1 << 26) : 0) | (v->tune.exp_noloop ? (1 << 27) : 0);
+    if (v->tune.quad_nt < 0 ? true : v->tune.quad_nt != 0) p->flags |= (1 << 28);
     const int64_t inplane = (int64_t)p->nTh * p->nTw;
     // chunk depth: every chunk pays one or two quad steps beyond its own planes (history of the first outputs, misaligned
     // ends), so chunks are deeper than the plain kernels' -- 64 planes = 16 steps + ~1.5
-    int target_dch = 64;
+    // [measured, tools/march_ab.py, 512^3 / 1024^3 sweeps] trilinear: 24 planes where a whole layer of tiles is resident at once
+    // (512^3: 0.204 vs 0.213 ms at 76; short-lived workgroups keep the write stream compact, tools/probes/pattern_probe.hip),
+    // 64 on larger planes (1024^3: 1.70 at 64, 1.77 at 32, 1.82 at 128); cubic: 64 (two extra steps per chunk: 512^3 0.238 at
+    // whole rounds of 256, 0.266 at 24)
+    int target_dch = (!cubic && (int64_t)v->H * v->W <= 512 * 512) ? 24 : 64;
+    const bool round_aware = cubic && v->tune.dch <= 0;
     if (v->tune.dch > 0) target_dch = std::max(4, v->tune.dch);
     int64_t nchunks = std::max<int64_t>(1, (v->oD + target_dch - 1) / target_dch);
     // small volumes: shorter chunks until the launch has ~4 workgroups per CU, not below 8 planes per chunk
@@ -605,7 +621,7 @@ bool plan_quad(vt_volume* v, const double m[12], int flags, AffineParams* p, Til
     nchunks = std::max<int64_t>(nchunks, n_addr);
     const int bpc = quad_blocks_per_cu(plan->cfg, v->interp, plan->lds_bytes);
     plan->blocks_per_cu = bpc;
-    if (v->tune.dch <= 0)
+    if (round_aware)
         nchunks = round_aware_chunks(v->oD, 4, inplane, (int64_t)v->cu_count * bpc, nchunks, 2 + halo2, 8, n_addr);
     int dch = (int)((v->oD + nchunks - 1) / nchunks);
     dch = (dch + 3) & ~3;

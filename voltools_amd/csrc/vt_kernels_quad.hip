@@ -32,12 +32,6 @@ namespace vt {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-// cache policy of the fast path's output stores (buffer-store aux bits: 0 plain, 2 nt).  [measured, tools/probes/pattern_probe.hip]
-// tile-shaped write-only streams: plain 5.5-5.7 TB/s, nt 5.2-5.4; in the full kernel see DESIGN.md section 5.
-#ifndef VT_QUAD_STORE_AUX
-#define VT_QUAD_STORE_AUX 2
-#endif
-
 // plain [z][y][P] -> quad layout [z/4][y][Pq]: element (z, y, x) at 4x + (z & 3) of row ((z >> 2), y); positions W .. Wq-1
 // of every row stay zero (the border colour; the staging loads fetch position W of row 0 for every out-of-volume vector)
 __global__ __launch_bounds__(256) void relayout_zquad(const float* __restrict__ src, float* __restrict__ dst,
@@ -220,6 +214,9 @@ __global__ __launch_bounds__(NT) void affine_march4(const float* __restrict__ sr
     {
         int* tab = reinterpret_cast<int*>(lds);   // [0..63] column min -> span start, [64..127] column max -> first vector, [128] total
         unsigned char* vrow = reinterpret_cast<unsigned char*>(tab + kTabInts);
+#ifdef VT_QUAD_ANALYTIC_SPANS                     // A/B: the float64 polygon clipping of the plain / pair marching kernels
+        build_span_table<TH, TW, HALO, 1>(tab, p, p.Ly, by, bx, tid);
+#else
         if (tid < 2 * kRowsMax) tab[tid] = (tid < kRowsMax) ? 0x7fffffff : (int)0x80000000;
         __syncthreads();
 #pragma unroll
@@ -257,6 +254,7 @@ __global__ __launch_bounds__(NT) void affine_march4(const float* __restrict__ sr
             for (int v = first; v < last; ++v) vrow[v] = (unsigned char)lane;
         }
         __syncthreads();
+#endif
         nvec = tab[2 * kRowsMax];
 #pragma unroll
         for (int it = 0; it < kMaxIt; ++it) {
@@ -313,6 +311,7 @@ __global__ __launch_bounds__(NT) void affine_march4(const float* __restrict__ sr
     // steps whose four outputs all belong to the chunk: quads Qf0 .. Qf1 (output d's newest tap plane is d + zoff + HALO + 1)
     const int tap_new = p.zoff + HALO + 1;
     const int Qf0 = floordiv4(d_begin + tap_new + 3), Qf1 = floordiv4(d_end - 4 + tap_new);
+    const bool nt_stores = (p.flags & (1 << 28)) != 0;       // streaming (nontemporal) output stores, chosen by the planner
     const bool tile_fast = all_valid && (h0 + TH <= p.oH) && (w0 + TW <= p.oW);
     char* const lds_c = reinterpret_cast<char*>(lds);
 #ifdef VT_EXPERIMENTS      // make EXTRA=-DVT_EXPERIMENTS: VT_EXP_NOSTORE / VT_EXP_NOLOAD / VT_EXP_NOLDS ablations
@@ -416,15 +415,29 @@ __global__ __launch_bounds__(NT) void affine_march4(const float* __restrict__ sr
             const int d_first = 4 * Q - tap_new;  // output plane whose newest tap plane is 4Q
             if (full) {
                 int soff = (d_first - d_begin) * oplane_bytes;
+                float val[4][NPIX];
 #pragma unroll
-                for (int i = 0; i < 4; ++i, soff += oplane_bytes) {
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int px = 0; px < NPIX; ++px) {
-                        const float val = zcombine(px, part[px][i]);
-                        // streaming stores: the output is written once and never read back by this launch
-                        if (no_stores) asm volatile("" ::"v"(val));
-                        else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), orsrc, ob[px], soff, VT_QUAD_STORE_AUX);
-                    }
+                    for (int px = 0; px < NPIX; ++px) val[i][px] = zcombine(px, part[px][i]);
+                // the cache policy of a store is an immediate of the instruction: two copies of the store block
+                if (no_stores) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int px = 0; px < NPIX; ++px) asm volatile("" ::"v"(val[i][px]));
+                } else if (nt_stores) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i, soff += oplane_bytes)
+#pragma unroll
+                        for (int px = 0; px < NPIX; ++px)
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val[i][px]), orsrc, ob[px], soff, 2);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i, soff += oplane_bytes)
+#pragma unroll
+                        for (int px = 0; px < NPIX; ++px)
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val[i][px]), orsrc, ob[px], soff, 0);
                 }
             } else {
 #pragma unroll
