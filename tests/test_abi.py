@@ -105,6 +105,6 @@ def test_host_result_pool_reuses_only_released_buffers(monkeypatch):
     del view, b, d
     pool.cap = 3 * 64 ** 3 * 4
     e = pool.take((65, 64, 64), 0)
-    assert sum(x.nbytes for x in pool.entries) <= pool.cap and e.shape == (65, 64, 64)
+    assert sum(x[3] for x in pool.entries) <= pool.cap and e.shape == (65, 64, 64)
     pool.clear()
     assert not fake.registered

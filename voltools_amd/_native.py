@@ -291,7 +291,7 @@ class _HostResultPool:
             if j < 0:
                 break
             victim = self.entries.pop(j)
-            load().vt_host_unregister(device, ctypes.c_void_p(self._addr(victim)))
+            self._unregister(device, victim)
             total -= victim[3]
             del victim
         entry = self._new_entry(n)
@@ -299,9 +299,15 @@ class _HostResultPool:
             self.entries.append(entry)
         return self._view(entry, shape)
 
+    def _unregister(self, device: int, entry) -> None:
+        rc = load().vt_host_unregister(device, ctypes.c_void_p(self._addr(entry)))
+        if rc != 0:                # someone else removed the registration: a bug worth hearing about, not worth failing a result for
+            import warnings
+            warnings.warn(f'host result pool: unregister of a {entry[3]}-byte buffer failed (code {rc})', RuntimeWarning)
+
     def clear(self, device: int = 0) -> None:
         for e in self.entries:
-            load().vt_host_unregister(device, ctypes.c_void_p(self._addr(e)))
+            self._unregister(device, e)
         self.entries = []
 
 

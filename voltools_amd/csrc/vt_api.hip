@@ -87,8 +87,10 @@ int fail(int code, const char* fmt, ...)
 #define VT_HIP(call)                                                                               \
     do {                                                                                           \
         hipError_t e_ = (call);                                                                    \
-        if (e_ != hipSuccess)                                                                      \
+        if (e_ != hipSuccess) {                                                                    \
+            (void)hipGetLastError();   /* the runtime's last-error is sticky: a failure reported here must not resurface at the next launch check */ \
             return fail((int)e_, "%s: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+        }                                                                                          \
     } while (0)
 
 int use_device(int dev)
@@ -408,10 +410,22 @@ namespace {
 struct PinnedScope {
     void* ptr = nullptr;
     bool pinned = false;
+    // Memory the runtime already knows as pinned host memory (the Python layer's pooled result buffers, a caller's own
+    // hipHostMalloc / hipHostRegister): registering the same range a second time SUCCEEDS, and the matching unregister at the
+    // end of the scope then strips the owner's registration ([measured] tools/diag/pin_trace.py: the pool's later
+    // hipHostUnregister failed with "pointer does not correspond to a registered memory region", and the sticky error
+    // failed the next kernel-launch check).
+    static bool already_registered(const void* p)
+    {
+        hipPointerAttribute_t attr;
+        const hipError_t e = hipPointerGetAttributes(&attr, p);
+        if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+        return attr.type == hipMemoryTypeHost;
+    }
     PinnedScope(const void* p, size_t bytes)
     {
         static const bool off = std::getenv("VT_NO_PIN") != nullptr;
-        if (!off && p && bytes >= (8u << 20)) {
+        if (!off && p && bytes >= (8u << 20) && !already_registered(p)) {
             // Whole pages only: registration pins and maps pages, and a range that starts or ends inside a page shares that
             // page with whatever else is registered on it (the Python layer's pooled result buffers, the runtime's own
             // temporary pins); unregistering one of the overlapping ranges unmaps the shared page under the others -> a GPU
