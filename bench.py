@@ -35,6 +35,7 @@ def parse():
     ap.add_argument('--interp', default='filt_bspline')
     ap.add_argument('--strong', action='store_true', help='strong scaling: ONE size^3 volume cut into axis-0 slabs over the '
                     'ranks (SURVEY 8d config 5); default is weak scaling, one size^3 slab per rank')
+    ap.add_argument('--prewarm-ms', type=float, default=250.0, help='untimed launches for at least this long before the timed steps')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target wall time of the CPU baseline sample')
     return ap.parse_args()
@@ -104,8 +105,24 @@ def measured_traffic(kernel_prefix):
     return best
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here, one per GPU, through torch.distributed.run --
+    BEFORE anything in this process touches the GPU (the parent never does) -- and exit with their code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        self_launch(args)
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -161,6 +178,20 @@ def main():
 
     for i in range(args.warmup):
         sv.affine(mats[i], output=out)
+    # Time-based pre-warm, outside `warmup` and `steps`: a 20-step run of 0.25 ms launches is over before the clocks have
+    # ramped (round 1: the driver's 20-step run read 11 % below the 180-step profile of the same kernel).
+    prewarm_ms = 0.0
+    if args.prewarm_ms > 0:
+        t_pw = time.perf_counter()
+        k = 0
+        while True:
+            for _ in range(32):
+                sv.affine(mats[k % len(mats)], output=out)
+                k += 1
+            sv.synchronize()
+            prewarm_ms = (time.perf_counter() - t_pw) * 1e3
+            if prewarm_ms >= args.prewarm_ms:
+                break
     barrier()
     sv.timer_start()
     t0 = time.perf_counter()
@@ -174,6 +205,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # per-step distribution (after the timed region, one event pair per launch): the sweep's angles differ by +-10 %
+    step_ms = []
+    for i in range(min(args.steps, 180)):
+        sv.timer_start()
+        sv.affine(mats[args.warmup + i], output=out)
+        step_ms.append(sv.timer_stop())
+    step_ms = np.asarray(step_ms)
+
     info = sv.info()
     vox_per_step = nd * n * n * world
     value = vox_per_step * args.steps / elapsed / 1e6
@@ -185,20 +224,21 @@ def main():
              4: f'vt::affine_march_zsep<{kind_code}', 5: f'vt::affine_march_zpair<{kind_code}', 8: f'vt::affine_march4<{kind_code}'}.get(int(info.last_kernel), 'vt::affine')
     traffic = measured_traffic('void ' + kname) if (n == 512 and world == 1) else None
     result = {
-        'metric': 'Mvoxels/s, 512^3 f32 filt_bspline StaticVolume transform (resident source, device output)',
+        'metric': f'Mvoxels/s, {n}^3 f32 {interp} StaticVolume transform (resident source, device output)',
         'value': round(value, 1), 'unit': 'Mvoxels/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'strong' if strong else 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': f'{n}^3 float32 {interp}, StaticVolume resident in HBM, rotate((0,i,0)) rzxz sweep, '
                                f'output= device buffer' + (f', {world} axis-0 slabs of {nd}x{n}x{n}' if world > 1 else ''),
                    'tile': list(info.last_tile), 'lds_bytes': int(info.last_lds_bytes), 'kernel': int(info.last_kernel),
-                   'prefilter_ms_once': round(float(info.prefilter_ms), 3)},
+                   'prefilter_ms_once': round(float(info.prefilter_ms), 3), 'prewarm_ms': round(prewarm_ms, 1)},
         'roofline': {'bound': 'hbm', 'kernel': kname, 'achieved': round(achieved, 1), 'peak': 8000.0,
                      'unit': 'GB/s', 'frac': round(achieved / 8000.0, 4),
                      'traffic': (round(traffic['bytes']) if traffic else None),
                      'traffic_source': (traffic['source'] if traffic else None),
                      'counters': (traffic['extra'] if traffic else None),
-                     'kernel_ms': round(kernel_ms, 4), 'algorithmic_bytes_per_launch': algo_bytes},
+                     'kernel_ms': round(kernel_ms, 4), 'kernel_ms_min': round(float(step_ms.min()), 4),
+                     'kernel_ms_median': round(float(np.median(step_ms)), 4), 'algorithmic_bytes_per_launch': algo_bytes},
     }
 
     if rank == 0 and world == 1:

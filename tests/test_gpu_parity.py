@@ -235,7 +235,10 @@ def test_keep_outside_and_zero_fill(interp):
 def test_prefilter_matches_oracle_all_axes_lengths():
     """Prefilter alone: line lengths below/at/above the chunk and segment sizes, on every axis."""
     lib = _native.load()
-    for shape in [(5, 7, 9), (12, 11, 13), (64, 65, 63), (130, 20, 70), (20, 200, 24), (24, 20, 300), (200, 17, 129)]:
+    # (the last four: rows of whole 16-byte vectors -> the block-form strided passes; one segment, segments with warm-up at
+    #  interior ends, partial last chunks, a last segment shorter than the warm-up)
+    for shape in [(5, 7, 9), (12, 11, 13), (64, 65, 63), (130, 20, 70), (20, 200, 24), (24, 20, 300), (200, 17, 129),
+                  (300, 260, 64), (100, 530, 32), (36, 257, 8), (270, 40, 260)]:
         vol = rand_vol(shape, 5)
         d = _native.DeviceArray.from_numpy(vol, 0)
         _native.check(lib.vt_prefilter_inplace(0, d.ptr, *shape), 'vt_prefilter_inplace')

@@ -317,6 +317,13 @@ struct Tuning {
 
 bool is_cubic(int interp) { return interp != VT_LINEAR; }
 
+// Row pitch of a resident plain-layout copy, in floats: the row's samples, at least one all-zero 16-byte vector after them
+// (the border fetch target), rounded up so that EVERY ROW STARTS ON A 128-BYTE CACHE LINE.  With the round-1 pitch
+// (roundup4(W) + 4: 2064 bytes at W = 512) every row segment a strided prefilter pass stores straddled cache lines:
+// partial-line writes, [measured] 2.0 instead of 5.2 TB/s for tile-shaped stores (tools/probes/pattern_probe.hip, pitch 520)
+// and 0.32 ms per strided pass at 512^3 whatever the load width.  Costs 6 % more resident bytes at 512, 3 % at 1024.
+int resident_pitch(int W) { return (W + 4 + 31) & ~31; }
+
 // Chunk count of a marching launch.  Its workgroups all do the same work, so the chip runs them in rounds of `resident`
 // workgroups and a launch of 5.33 rounds takes almost as long as one of 6 ([measured] 512^3 cubic at 0 / 30 degrees:
 // 8 chunks = 5.33 rounds 0.274 / 0.304 ms; 6 chunks = 4.0 rounds 0.261 / 0.296; 3 chunks = 2.0 rounds 0.249 / 0.297;
@@ -623,8 +630,9 @@ bool plan_quad(vt_volume* v, const double m[12], int flags, AffineParams* p, Til
     // (512^3: 0.204 vs 0.213 ms at 76; short-lived workgroups keep the write stream compact, tools/probes/pattern_probe.hip),
     // 64 on larger planes (1024^3: 1.70 at 64, 1.77 at 32, 1.82 at 128); cubic: 64 (two extra steps per chunk: 512^3 0.238 at
     // whole rounds of 256, 0.266 at 24)
+    // (cubic, after chunk starts were aligned to quads -- dshift below: 512^3 0.227 ms at 64 planes, 0.233 at 128, 0.236 at 256)
     int target_dch = (!cubic && (int64_t)v->H * v->W <= 512 * 512) ? 24 : 64;
-    const bool round_aware = cubic && v->tune.dch <= 0;
+    const bool round_aware = false;
     if (v->tune.dch > 0) target_dch = std::max(4, v->tune.dch);
     int64_t nchunks = std::max<int64_t>(1, (v->oD + target_dch - 1) / target_dch);
     // small volumes: shorter chunks until the launch has ~4 workgroups per CU, not below 8 planes per chunk
@@ -639,9 +647,13 @@ bool plan_quad(vt_volume* v, const double m[12], int flags, AffineParams* p, Til
         nchunks = round_aware_chunks(v->oD, 4, inplane, (int64_t)v->cu_count * bpc, nchunks, 2 + halo2, 8, n_addr);
     int dch = (int)((v->oD + nchunks - 1) / nchunks);
     dch = (dch + 3) & ~3;
-    nchunks = (v->oD + dch - 1) / dch;
-    if ((int64_t)dch * max_stride * 4 >= 0x7fffffffLL) { plan->kind = 1; return false; }
+    // chunk boundaries at c*dch + dshift: the first tap plane of every chunk but the first, d_begin + zoff - halo, is then the
+    // first plane of a quad -- a cubic chunk marches dch/4 + 1 quads instead of dch/4 + 2 (64 planes: 17 steps instead of 18)
+    const int dshift = (int)((((int64_t)halo - (int64_t)p->zoff) % 4 + 4) % 4);
+    nchunks = (v->oD > dshift) ? (v->oD - dshift + dch - 1) / dch : 1;
+    if ((int64_t)(dch + dshift) * max_stride * 4 >= 0x7fffffffLL) { plan->kind = 1; return false; }
     p->dch = dch;
+    p->dshift = dshift;
     p->nTd = (int)nchunks;
     if (v->tune.blk_h > 0 && v->tune.blk_w > 0) { p->blk_h = v->tune.blk_h; p->blk_w = v->tune.blk_w; }
     const int64_t grid = inplane * nchunks;
@@ -1147,7 +1159,7 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
     if (xsep) {
         vt_volume sw;
         sw.dev = v->dev; sw.interp = v->interp;
-        sw.D = v->W; sw.H = v->H; sw.W = v->D; sw.P = ((v->D + 3) & ~3) + 4;
+        sw.D = v->W; sw.H = v->H; sw.W = v->D; sw.P = resident_pitch(v->D);
         sw.oD = v->oW; sw.oH = v->oH; sw.oW = v->oD;
         sw.plane0 = 0; sw.gD = v->W; sw.out_plane0 = 0;
         sw.lds_limit = v->lds_limit; sw.cu_count = v->cu_count; sw.tune = v->tune;
@@ -1203,7 +1215,7 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
     if (rsep) {
         vt_volume sw;
         sw.dev = v->dev; sw.interp = v->interp;
-        sw.D = v->D; sw.H = v->W; sw.W = v->H; sw.P = ((v->H + 3) & ~3) + 4;
+        sw.D = v->D; sw.H = v->W; sw.W = v->H; sw.P = resident_pitch(v->H);
         sw.oD = v->oD; sw.oH = v->oH; sw.oW = v->oW;
         sw.plane0 = v->plane0; sw.gD = v->gD; sw.out_plane0 = v->out_plane0;
         sw.lds_limit = v->lds_limit; sw.cu_count = v->cu_count; sw.tune = v->tune;
@@ -1371,7 +1383,7 @@ int create_common(int dev, int D, int H, int W, int interp, const float* data, i
     VT_HIPC(cached_event(dev, &v->ev1));
     // resident layout: rows padded to a multiple of 4 floats so every row starts 16-byte aligned (the tiled
     // kernel stages with 16-byte direct-to-LDS loads); pad columns are zero = the border value
-    v->P = ((W + 3) & ~3) + 4;         // + one guaranteed zero vector per row (border fetch target)
+    v->P = resident_pitch(W);
     const size_t bytes = (size_t)D * H * v->P * sizeof(float);
     VT_HIPC(cached_malloc(dev, reinterpret_cast<void**>(&v->d_src), bytes));
     v->src_bytes = bytes;

@@ -44,6 +44,8 @@ struct AffineParams {
     int blk_h, blk_w;          // marching kernels: blocked tile order inside a chunk layer (tiles per block; 0 = plain order)
     int32_t sPq;               // plane-quad layout: floats per quad-row (4 * positions per row)
     int32_t zero_off_q;        // plane-quad layout: byte offset of a zero vector inside any quad-plane
+    int32_t dshift;            // plane-quad kernel: chunk c > 0 starts at output plane c*dch + dshift (0..3), chosen so that a chunk's first
+                               // tap plane is the first plane of a quad (one quad step per chunk beyond its own planes instead of two)
 };
 
 

@@ -309,6 +309,142 @@ __global__ __launch_bounds__(256) void prefilter_chunked(const float* __restrict
     }
 }
 
+
+// ---- strided passes, block form: a 1024-thread workgroup owns 256 columns x one segment of a line set, in registers ----
+// The chunked kernel above loads 4 bytes per lane and re-reads 2 x 16 warm-up samples per 128-sample chunk (1.25-1.32x the
+// samples: [measured] 3.4 TB/s of algorithmic traffic, 42 % of peak).  Here lanes run along x with 16 bytes each (a wave moves
+// 1 KiB per instruction), the 16 waves of the workgroup split a segment of <= 16*CW consecutive samples of the line into
+// chunks of CW, every wave runs the recursion on its chunk with zero carry-in, and the carries between chunks are combined
+// EXACTLY through LDS: with g = z^CW the true carry into chunk w is sum_j g^(w-1-j) e_j over the local end states e_j of the
+// chunks before it (Horner; the terms die out after one or two chunks but nothing is assumed).  Then y[k] += z^(k+1) carry.
+// The anticausal sweep does the same from the other side.  Lines longer than one segment are cut into segments with
+// K = 16 samples of warm-up at interior ends (|z|^16 = 7e-10), as the chunked kernel does for every chunk: 32 extra samples per
+// 256 instead of per 128 -- and those re-reads meet the neighbouring segment's loads in L2.
+// Same arithmetic per sample as bspline.h:30-54 (reference initialisations at true line ends), re-associated like the X pass.
+constexpr int kBlkK = 16;           // warm-up samples at interior segment ends
+// (waves, samples per wave): a workgroup covers NW*CW - 2*K samples of a line.  16 x 18 = 256 + 32 with one 1024-thread
+// workgroup per CU; 8 x 20 = 128 + 32 with two 512-thread workgroups per CU (one loads while the other stores)
+
+__device__ __forceinline__ float4 f4_fma(float a, const float4& b, const float4& c)
+{
+    return make_float4(fmaf(a, b.x, c.x), fmaf(a, b.y, c.y), fmaf(a, b.z, c.z), fmaf(a, b.w, c.w));
+}
+__device__ __forceinline__ float4 f4_scale(float a, const float4& b) { return make_float4(a * b.x, a * b.y, a * b.z, a * b.w); }
+
+template <int NW, int kBlkCW>
+__global__ __launch_bounds__(64 * NW, 4) void prefilter_block(const float* __restrict__ src, float* __restrict__ dst,
+                                                          int N, int64_t es,          // line length, element stride along the line
+                                                          int nA4,                    // columns / 4 (lane axis, contiguous, 16-byte vectors)
+                                                          int nB, int64_t sB,         // outer axis
+                                                          int nseg, int lo_interior)
+{
+    constexpr int kBlkSeg = NW * kBlkCW - 2 * kBlkK;
+    static_assert(kBlkCW >= 12, "the causal initialisation reads the first 12 samples from one chunk");
+    __shared__ float4 ends[NW][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int ncb = (nA4 + 63) >> 6;
+    int t = blockIdx.x;
+    const int cb = t % ncb; t /= ncb;
+    const int bi = t % nB;
+    const int seg = t / nB;                                   // segment of the line
+    const int col4 = cb * 64 + lane;
+    const bool active = col4 < nA4;
+    const int64_t base = (int64_t)bi * sB + 4 * (int64_t)(active ? col4 : nA4 - 1);
+    const float* s = src + base;
+    float* o = dst + base;
+
+    // positions of this workgroup: [a0, b0) are written; [la, lb) are loaded (warm-up at interior ends)
+    const int a0 = seg * kBlkSeg, b0 = min(a0 + kBlkSeg, N);
+    const int la = (seg > 0) ? a0 - kBlkK : 0;
+    const int lb = min(b0 + ((b0 < N) ? kBlkK : 0), N);
+    const int my0 = la + w * kBlkCW;                          // this wave's chunk [my0, my0 + CW) clipped to lb
+    const int cnt = max(0, min(kBlkCW, lb - my0));
+
+    float4 v[kBlkCW];
+#pragma unroll
+    for (int k = 0; k < kBlkCW; ++k)
+        v[k] = (k < cnt) ? *reinterpret_cast<const float4*>(s + (int64_t)(my0 + k) * es) : make_float4(0.f, 0.f, 0.f, 0.f);
+
+    constexpr float z1 = kPole;
+    float g = 1.0f;                                           // z^CW
+#pragma unroll
+    for (int k = 0; k < kBlkCW; ++k) g *= z1;
+
+    // ---- causal: y[k] = L v[k] + z y[k-1] ----
+    const bool line_start = (my0 == 0) && cnt > 0;            // this chunk holds sample 0 of the line (wave 0 of segment 0)
+    if (line_start) {
+        float4 init;
+        if (!lo_interior) {
+            // bspline.h:2-19: s[0] + sum_{n < min(12, N)} z^(n+1) s[n]   (kBlkCW >= 12: all inside this chunk)
+            float4 sum = v[0];
+            float zn = z1;
+#pragma unroll
+            for (int n = 0; n < 12; ++n) {
+                if (n < N) sum = f4_fma(zn, v[n], sum);
+                zn *= z1;
+            }
+            init = f4_scale(kLambda, sum);
+        } else {
+            init = f4_scale(kLambda * (1.0f / (1.0f - kPole)), v[0]);
+        }
+        v[0] = init;
+    } else {
+        // interior start: zero carry-in now, the true carry is added below.  The very first loaded sample of a segment that
+        // starts inside the line begins from the steady state of a constant signal (forgotten after K samples).
+        if (w == 0 && cnt > 0) v[0] = f4_scale(kLambda * (1.0f / (1.0f - kPole)), v[0]);
+        else v[0] = f4_scale(kLambda, v[0]);
+    }
+#pragma unroll
+    for (int k = 1; k < kBlkCW; ++k) v[k] = f4_fma(z1, v[k - 1], f4_scale(kLambda, v[k]));
+    // end state of this chunk (the value at its last valid sample; later samples are padding: their "state" keeps decaying,
+    // which is exactly what the carry formula wants when cnt == CW; a partial chunk is always the last one and feeds nobody)
+    ends[w][lane] = v[kBlkCW - 1];
+    __syncthreads();
+    if (w > 0) {
+        float4 c = ends[0][lane];
+        for (int j = 1; j < w; ++j) c = f4_fma(g, c, ends[j][lane]);
+        float zk = z1;
+#pragma unroll
+        for (int k = 0; k < kBlkCW; ++k) { v[k] = f4_fma(zk, c, v[k]); zk *= z1; }
+    }
+    __syncthreads();
+
+    // ---- anticausal: c[n] = u[n] + z c[n+1];  u[N-1] = z/(z-1) c+[N-1], u[n < N-1] = -z c+[n] ----
+    // local sweep with zero carry-in from above; positions >= lb are padding (u = 0)
+    {
+        float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = kBlkCW - 1; k >= 0; --k) {
+            const int pos = my0 + k;
+            float4 u;
+            if (k >= cnt) u = make_float4(0.f, 0.f, 0.f, 0.f);
+            else if (pos == N - 1) u = f4_scale(kAntiInit, v[k]);
+            else if (pos == lb - 1) u = f4_scale(kAntiInit, v[k]);        // interior end of a segment: steady-state guess, forgotten after K samples
+            else u = f4_scale(-z1, v[k]);
+            c = f4_fma(z1, c, u);
+            v[k] = c;
+        }
+    }
+    ends[w][lane] = v[0];
+    __syncthreads();
+    if (w < NW - 1) {
+        float4 c = ends[NW - 1][lane];
+        for (int j = NW - 2; j > w; --j) c = f4_fma(g, c, ends[j][lane]);
+        // v[k] += z^(CW - k) * carry  (carry = true value of the next chunk's first sample)
+        float zk = z1;
+#pragma unroll
+        for (int k = kBlkCW - 1; k >= 0; --k) { v[k] = f4_fma(zk, c, v[k]); zk *= z1; }
+    }
+
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < kBlkCW; ++k) {
+            const int pos = my0 + k;
+            if (k < cnt && pos >= a0 && pos < b0) *reinterpret_cast<float4*>(o + (int64_t)pos * es) = v[k];
+        }
+    }
+}
+
 constexpr int kChunk = 64, kWarm = 16;
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
@@ -386,6 +522,29 @@ hipError_t launch_prefilter_axis(int axis, const float* src, float* dst, int D, 
         else if (nseg <= 16) hipLaunchKernelGGL(prefilter_x_scan<16>, g, b, 0, stream, src, dst, W, pitch, nlines, li);
         else hipLaunchKernelGGL(prefilter_x_scan<32>, g, b, 0, stream, src, dst, W, pitch, nlines, li);
         return hipGetLastError();
+    }
+    static const bool no_block = getenv("VT_PF_NO_BLOCK") != nullptr;
+    static const int blk_variant = env_int("VT_PF_BLOCK", 0);
+    if (!no_block && axis != 2 && src != dst && (pitch & 3) == 0 && pitch >= ((W + 3) & ~3) &&
+        ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0 && (axis == 1 ? H : D) >= 40) {
+        // block form (16 bytes per lane, exact carries): rows are 16-byte aligned and padded to whole vectors (the pad columns
+        // are filtered along with the rest: zeros stay zeros)
+        const int N = axis == 1 ? H : D;
+        const int64_t es = axis == 1 ? (int64_t)pitch : plane;
+        const int nB = axis == 1 ? D : H;
+        const int64_t sB = axis == 1 ? plane : (int64_t)pitch;
+        const int nA4 = ((W + 3) & ~3) / 4;
+        auto launch = [&](auto kern, int nw, int cw) -> hipError_t {
+            const int seg = nw * cw - 2 * kBlkK;
+            const int nseg = (N + seg - 1) / seg;
+            const int64_t blocks = (int64_t)((nA4 + 63) / 64) * nB * nseg;
+            if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * nw), 0, stream, src, dst, N, es, nA4, nB, sB, nseg, lo_interior ? 1 : 0);
+            return hipGetLastError();
+        };
+        if (blk_variant == 1) return launch(prefilter_block<8, 20>, 8, 20);
+        if (blk_variant == 2) return launch(prefilter_block<8, 18>, 8, 18);
+        return launch(prefilter_block<16, 18>, 16, 18);
     }
     int N, nA, nB;
     int64_t es, sA, sB;

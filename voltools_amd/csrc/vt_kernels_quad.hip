@@ -133,8 +133,8 @@ __global__ __launch_bounds__(NT) void affine_march4(const float* __restrict__ sr
     int tw_i, th_i, chunk;
     march_tile(p, t, th_i, tw_i, chunk);
     const int h0 = th_i * TH, w0 = tw_i * TW;
-    const int d_begin = chunk * p.dch;
-    const int d_end = min(d_begin + p.dch, p.oD);
+    const int d_begin = chunk ? chunk * p.dch + p.dshift : 0;
+    const int d_end = min((chunk + 1) * p.dch + p.dshift, p.oD);
 
     // in-plane footprint (rows 1, 2; column 0 of the matrix is zero)
     double base[3], lo[3], hi[3];
