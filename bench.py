@@ -78,12 +78,16 @@ def cpu_baseline(vol, interp, matrices, target_s):
     return res
 
 
-def measured_traffic(kernel_prefix):
-    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (profiles/*_summary.json,
-    produced by tools/profile_bench.sh on this same command), FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes."""
+def measured_traffic(kernel_prefix, case):
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes of the SAME command
+    (profiles/rNN_<case>_summary.json, written by tools/profile_round.sh: separate --pmc passes, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  The newest round's file wins."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_summary.json'))):
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r*_{case}_summary.json')))
+    if case == 'bench':
+        files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r01_summary.json'))) + files      # round 1's name for it
+    for f in files:
         try:
             d = json.load(open(f))
         except Exception:
@@ -222,7 +226,8 @@ def main():
     kind_code = {'linear': 0, 'bspline': 1, 'filt_bspline': 1}.get(interp, 2)
     kname = {1: f'vt::affine_direct<{kind_code}>', 2: f'vt::affine_tiled<{kind_code}', 3: f'vt::affine_tiled_zsep<{kind_code}',
              4: f'vt::affine_march_zsep<{kind_code}', 5: f'vt::affine_march_zpair<{kind_code}', 8: f'vt::affine_march4<{kind_code}'}.get(int(info.last_kernel), 'vt::affine')
-    traffic = measured_traffic('void ' + kname) if (n == 512 and world == 1) else None
+    case = 'bench' if (n == 512 and interp == 'filt_bspline') else ('sweep1024' if (n == 1024 and interp == 'filt_bspline') else None)
+    traffic = measured_traffic('void ' + kname, case) if (case and world == 1) else None
     result = {
         'metric': f'Mvoxels/s, {n}^3 f32 {interp} StaticVolume transform (resident source, device output)',
         'value': round(value, 1), 'unit': 'Mvoxels/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
