@@ -1,6 +1,7 @@
 // vt_api.hip -- the C ABI of include/voltools_hip.h (hipMalloc / hipMemcpyAsync / kernel launches).
 #include "vt_internal.h"
 #include "vt_device.h"
+#include "vt_host.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -278,136 +279,7 @@ int init_device(int dev)
     return 0;
 }
 
-// Experiment overrides, read from the environment once per handle (vt_volume_create) -- never on the per-call path.
-// None is needed in production; tools/*.sh and the staging-mode parity test use them to reach planner alternatives.
-struct Tuning {
-    int tile = -1;                 // VT_TILE: force tile configuration (index into the kernel family's table)
-    int la = 0;                    // VT_LA: planes / pairs staged ahead by the marching kernels
-    int march_box = -1;            // VT_MARCH_BOX: 1 = bounding-box staging, 0 = packed row spans, -1 = planner's choice
-    int lxpad = -1;                // VT_LXPAD: LDS row padding of the pair kernel's boxes
-    int dch = 0;                   // VT_DCH: output planes per marching chunk
-    int blk_h = -1, blk_w = -1;    // VT_BLK_H / VT_BLK_W: blocked tile order of the marching kernels (tiles per block; 0 = plain order)
-    bool plain_tile_order = false; // VT_TILE_ORDER=0: packed kernel walks tiles in plain instead of blocked order
-    bool rswap_wfast = false;      // VT_RSWAP_WFAST: keep the w-fastest tile order on the in-plane transposed copy
-    bool exp_nostore = false;      // VT_EXP_NOSTORE / VT_EXP_NOLOAD / VT_EXP_NOLDS: ablation builds (-DVT_EXPERIMENTS) only
-    bool exp_noload = false;
-    bool exp_nolds = false;
-    bool exp_noloop = false;
-    int quad_nt = -1;              // VT_QUAD_NT: 1 / 0 = nontemporal / plain output stores of the plane-quad kernel, -1 = planner's choice
-    void read()
-    {
-        auto num = [](const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; };
-        tile = num("VT_TILE", -1);
-        la = num("VT_LA", 0);
-        march_box = num("VT_MARCH_BOX", -1);
-        if (march_box > 1) march_box = 1;
-        lxpad = num("VT_LXPAD", -1);
-        dch = std::max(0, num("VT_DCH", 0));
-        blk_h = num("VT_BLK_H", -1);
-        blk_w = num("VT_BLK_W", -1);
-        plain_tile_order = num("VT_TILE_ORDER", 1) == 0;
-        rswap_wfast = std::getenv("VT_RSWAP_WFAST") != nullptr;
-        exp_nostore = std::getenv("VT_EXP_NOSTORE") != nullptr;
-        exp_noload = std::getenv("VT_EXP_NOLOAD") != nullptr;
-        exp_nolds = std::getenv("VT_EXP_NOLDS") != nullptr;
-        exp_noloop = std::getenv("VT_EXP_NOLOOP") != nullptr;
-        quad_nt = num("VT_QUAD_NT", -1);
-    }
-};
-
-bool is_cubic(int interp) { return interp != VT_LINEAR; }
-
-// Row pitch of a resident plain-layout copy, in floats: the row's samples, at least one all-zero 16-byte vector after them
-// (the border fetch target), rounded up so that EVERY ROW STARTS ON A 128-BYTE CACHE LINE.  With the round-1 pitch
-// (roundup4(W) + 4: 2064 bytes at W = 512) every row segment a strided prefilter pass stores straddled cache lines:
-// partial-line writes, [measured] 2.0 instead of 5.2 TB/s for tile-shaped stores (tools/probes/pattern_probe.hip, pitch 520)
-// and 0.32 ms per strided pass at 512^3 whatever the load width.  Costs 6 % more resident bytes at 512, 3 % at 1024.
-int resident_pitch(int W) { return (W + 4 + 31) & ~31; }
-
-// Chunk count of a marching launch.  Its workgroups all do the same work, so the chip runs them in rounds of `resident`
-// workgroups and a launch of 5.33 rounds takes almost as long as one of 6 ([measured] 512^3 cubic at 0 / 30 degrees:
-// 8 chunks = 5.33 rounds 0.274 / 0.304 ms; 6 chunks = 4.0 rounds 0.261 / 0.296; 3 chunks = 2.0 rounds 0.249 / 0.297;
-// 4 chunks = 2.67 rounds 0.260 / 0.314; tools/dch_rounds.sh).  Among chunk counts from n0/4 to 2*n0 take the one with the
-// least rounds x planes marched per chunk, a partial round charged at its fraction + 0.3; launches of many rounds (>= 16)
-// or of less than one keep n0, and so do planes with more tiles than the chip keeps resident (there deeper chunks
-// separate in-plane neighbours in time and their shared rows miss L2: 640^3 cubic 0.544 vs 0.498 ms).  Used by the pair
-// kernel only ([measured] 256^3 -9..-12 %, 384^3 -6..-10 %, 512^3 -2..-8 %).  `extra` = source planes a chunk stages beyond
-// its output planes.
-int64_t round_aware_chunks(int64_t oD, int g, int64_t inplane, int64_t resident, int64_t n0, int extra, int min_dch, int64_t n_floor)
-{
-    if (resident <= 0 || inplane > resident || inplane * n0 >= 16 * resident) return n0;
-    auto cost = [&](int64_t n) {
-        int64_t dch = (oD + n - 1) / n;
-        dch = (dch + g - 1) / g * g;
-        const int64_t n_act = (oD + dch - 1) / dch;
-        const double R = (double)(inplane * n_act) / (double)resident;
-        if (R < 1.0) return 1e300;
-        const double fl = std::floor(R), fr = R - fl;
-        return (fl + (fr > 1e-9 ? std::min(1.0, fr + 0.3) : 0.0)) * (double)(dch + extra);
-    };
-    int64_t best = n0;
-    double best_c = cost(n0);
-    if (best_c >= 1e300) return n0;
-    best_c *= 0.97;                                   // switch only for a predicted gain of 3 % or more
-    const int64_t lo = std::max<int64_t>(std::max<int64_t>(1, n_floor), n0 / 4);
-    const int64_t hi = std::min<int64_t>(2 * n0, std::max<int64_t>(1, oD / std::max(1, min_dch)));
-    for (int64_t n = hi; n >= lo; --n) {
-        const double c = cost(n);
-        if (c < best_c) { best_c = c; best = n; }
-    }
-    return best;
-}
-bool is_filtered(int interp) { return interp == VT_FILT_BSPLINE || interp == VT_FILT_BSPLINE_SIMPLE; }
-
 }  // namespace
-
-struct vt_volume {
-    int dev = 0;
-    int interp = 0;
-    int D = 0, H = 0, W = 0;           // resident source dims
-    int oD = 0, oH = 0, oW = 0;        // output dims
-    int64_t plane0 = 0;                // global index of resident plane 0
-    int64_t gD = 0;                    // global depth
-    int64_t out_plane0 = 0;            // global index of output plane 0
-    int P = 0;                         // row pitch of d_src in floats: W rounded up to 4, pad columns hold 0
-    float* d_src = nullptr;
-    size_t src_bytes = 0;              // size of the d_src allocation (small ones are recycled per device)
-    float* d_zeros = nullptr;          // 16 bytes of zeros: the border fetch target of the tiled kernel
-    float* d_src_zp = nullptr;         // second resident copy, planes interleaved in pairs (cubic marching kernel); lazy
-    float* d_src_t = nullptr;          // resident copy with axes 0 and 1 exchanged (rotations about axis 1 march along it); lazy
-    float* d_src_t_zp = nullptr;       // ... and its plane-pair form; lazy
-    float* d_src_r = nullptr;          // resident copy transposed in-plane ([z][x][y], pitch Pr; quarter-turn class of in-plane maps); lazy
-    float* d_src_r_zp = nullptr;       // ... and its plane-pair form; lazy
-    int Pr = 0;
-    float* d_src_x = nullptr;          // resident copy with axes 0 and 2 exchanged ([x][y][z], pitch Px; rotations about axis 2); lazy
-    float* d_src_x_zp = nullptr;       // ... and its plane-pair form; lazy
-    int Px = 0;
-    float* d_tmp_x = nullptr;          // exchanged result of an axis-2 launch, before it is turned back
-    size_t tmp_x_elems = 0;
-    float* d_src_q = nullptr;          // plane-quad copies ([z/4][y][x][4]; vt_kernels_quad.hip) of the four orientations; lazy
-    float* d_src_t_q = nullptr;
-    float* d_src_r_q = nullptr;
-    float* d_src_x_q = nullptr;
-    size_t quad_bytes[4] = {0, 0, 0, 0};   // allocation sizes of the four quad copies (vt_volume_info)
-    int P2 = 0;                        // floats per pair-row of d_src_zp
-    float* d_scratch_out = nullptr;    // staging for host outputs
-    double* d_batch_m = nullptr;       // batch launches: n x 12 folded matrices
-    std::vector<double> h_batch_m;     // ... and their host staging (must outlive the asynchronous upload)
-    size_t batch_m_cap = 0;
-    float* d_proj_tmp = nullptr;       // projection of general matrices: the transformed volume before the sum
-    size_t proj_tmp_elems = 0;
-    vt_volume* proj = nullptr;         // projection helper: 3 x H x W volume [S, S, S] sharing this handle's stream
-    bool owns_stream = true;
-    size_t scratch_elems = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    float prefilter_ms = 0.f;
-    int lds_limit = 160 * 1024;
-    int cu_count = 256;
-    // last launch, for vt_volume_info
-    int last_kernel = 0, last_tile[3] = {0, 0, 0}, last_lds[3] = {0, 0, 0}, last_lds_bytes = 0, last_grid = 0;
-    Tuning tune;                       // experiment overrides (environment, read at create)
-};
 
 namespace {
 
@@ -470,607 +342,233 @@ int run_prefilter(float* d_a, float* d_b, int D, int H, int W, int P, bool lo_in
     return 0;
 }
 
-// Expected LDS cycles of one half-wave `ds_read2_b32` of the gather (relative to conflict-free = 1.0) when lanes
-// step by (a, b) in (row, column) through an LDS image with row stride Lx: for each of the two dwords, the number
-// of distinct addresses on the busiest of the 32 banks (identical addresses broadcast).  Averaged over a few
-// sub-voxel offsets.  Used to choose the row stride of the marching cubic kernels, which are LDS-bound.
-double gather_conflict_factor(double a, double b, int Lx, int ndw = 2)
-{
-    double total = 0;
-    int samples = 0;
-    for (int oy = 0; oy < 2; ++oy)
-        for (int ox = 0; ox < 2; ++ox) {
-            const double y0 = 8.0 + 0.37 * oy + 40.0 * std::fabs(std::min(a, 0.0)), x0 = 8.0 + 0.41 * ox + 40.0 * std::fabs(std::min(b, 0.0));
-            for (int dw = 0; dw < ndw; ++dw) {
-                int count[32];
-                int addrs[32][32];
-                for (int i = 0; i < 32; ++i) count[i] = 0;
-                for (int l = 0; l < 32; ++l) {
-                    const int addr = (int)std::floor(y0 + a * l) * Lx + (int)std::floor(x0 + b * l) + dw;
-                    const int bank = addr & 31;
-                    bool seen = false;
-                    for (int k = 0; k < count[bank]; ++k) seen = seen || (addrs[bank][k] == addr);
-                    if (!seen) addrs[bank][count[bank]++] = addr;
-                }
-                int worst = 1;
-                for (int i = 0; i < 32; ++i) worst = std::max(worst, count[i]);
-                total += worst;
-                ++samples;
-            }
-        }
-    return total / samples;
-}
+// ---------------------------------------------------------------------------------------------------
+// one transform call: fold offsets -> pick the resident copy and the plan -> launch -> (host output) copy back
+// ---------------------------------------------------------------------------------------------------
 
-// Upper estimate of the packed footprint of a TH x TW in-plane tile (16-byte vectors per source plane) under rows 1, 2 of
-// the matrix, as the marching kernel packs it: per source row the tapped span, aligned to 16 bytes.  The tile's sub-voxel
-// position varies from tile to tile, so a 4 x 4 grid of offsets is sampled and a margin added; a tile that still exceeds
-// the slot falls back to a direct gather inside the kernel, so the estimate affects speed only.
-int estimate_packed_vectors(const double m[12], int th, int tw, int halo, int rows_cap, int* rows_out)
-{
-    const double a1 = m[5], b1 = m[6], a2 = m[9], b2 = m[10];       // d(sy)/dj, d(sy)/dk, d(sx)/dj, d(sx)/dk
-    const double ia1 = march_recip(a1), ib1 = march_recip(b1);
-    double neg1 = 0, neg2 = 0;
-    for (double e : {a1 * (th - 1), b1 * (tw - 1)}) if (e < 0) neg1 += e;
-    for (double e : {a2 * (th - 1), b2 * (tw - 1)}) if (e < 0) neg2 += e;
-    int worst = 0, worst_rows = 0;
-    for (int oy = 0; oy < 3; ++oy)
-        for (int ox = 0; ox < 3; ++ox) {
-            // box-relative base exactly as the kernel forms it: lo = base + neg, o = floor(lo) - halo, b = base - o
-            const double fy0 = 0.33 * oy + 0.013, fx0 = 0.33 * ox + 0.017;
-            const double by = fy0 - neg1 + halo, bx = fx0 - neg2 + halo;   // (+ up to 3 for the 16-byte alignment of o2)
-            int total = 0, rows = 0;
-            for (int Y = 0; Y < rows_cap; ++Y) {       // rows_cap: the bounding box's rows (+1)
-                int mn, mx;
-                if (!march_row_span(a1, b1, a2, b2, ia1, ib1, by, bx, Y, th, tw, halo, &mn, &mx)) continue;
-                total += ((mx - mn) >> 2) + 2;                   // +1 vector: unknown 16-byte phase of the span start
-                rows = Y + 1;
-            }
-            worst = std::max(worst, total);
-            worst_rows = std::max(worst_rows, rows);
-        }
-    *rows_out = worst_rows + 1;
-    return worst + worst / 64 + 2;
-}
+// Which resident copy a launch samples, and what is special about its output.
+struct Orientation {
+    const float* src_plain = nullptr;  // plain-layout copy the launch (or its pair / quad relayout) is based on
+    float** pair_slot = nullptr;       // where its plane-pair form lives
+    float** quad_slot = nullptr;       // where its plane-quad form lives
+    int quad_idx = 0;
+    int srcD = 0, srcH = 0;            // depth / height of that copy
+    int pair_W = 0, pair_P = 0;        // row width / pitch of that copy
+    bool xswap = false;                // the kernels write an axis-0 <-> 2 exchanged result into d_tmp_x
+};
 
-// Upper estimate of the packed footprint of a TH x TW in-plane tile in POSITIONS (plane-quad layout: one 16-byte vector per
-// position, no alignment), as affine_march4 packs it.  A 3 x 3 grid of sub-voxel offsets is sampled; a row's span changes by
-// at most one position with the offset, hence the margin of one position per row.  A tile that still exceeds the slot
-// takes the kernel's direct-gather path (slow, never wrong).
-int estimate_span_positions(const double m[12], int th, int tw, int halo, int rows_cap, int* rows_out)
-{
-    const double a1 = m[5], b1 = m[6], a2 = m[9], b2 = m[10];
-    const double ia1 = march_recip(a1), ib1 = march_recip(b1);
-    double neg1 = 0, neg2 = 0;
-    for (double e : {a1 * (th - 1), b1 * (tw - 1)}) if (e < 0) neg1 += e;
-    for (double e : {a2 * (th - 1), b2 * (tw - 1)}) if (e < 0) neg2 += e;
-    int worst = 0, worst_rows = 0;
-    for (int oy = 0; oy < 3; ++oy)
-        for (int ox = 0; ox < 3; ++ox) {
-            const double by = 0.33 * oy + 0.013 - neg1 + halo, bx = 0.33 * ox + 0.017 - neg2 + halo;
-            int total = 0, rows = 0;
-            for (int Y = 0; Y < rows_cap; ++Y) {
-                int mn, mx;
-                if (!march_row_span(a1, b1, a2, b2, ia1, ib1, by, bx, Y, th, tw, halo, &mn, &mx)) continue;
-                total += mx - mn + 1;
-                rows = Y + 1;
-            }
-            worst = std::max(worst, total);
-            worst_rows = std::max(worst_rows, rows);
-        }
-    *rows_out = worst_rows + 1;
-    return worst + worst_rows + 8;
-}
+bool is_marching(int kind) { return kind == 4 || kind == 5 || kind == 8; }
 
-// Marching kernel on the plane-quad layout (kind 8; vt_kernels_quad.hip) for an axis-0-separable matrix.  Returns false when
-// no configuration fits (the caller goes on to the plain / plane-pair marching kernels).
-bool plan_quad(vt_volume* v, const double m[12], int flags, AffineParams* p, TilePlan* plan)
+// src_resident = M . (d + out_plane0, h, w, 1) - (plane0, 0, 0): output-plane and resident-window offsets go into column 3
+void fold_matrix(const vt_volume* v, const double m4x4[16], double m[12])
 {
-    const bool cubic = is_cubic(v->interp);
-    const int halo = cubic ? 1 : 0, halo2 = 2 * halo;
-    const int Wq = (v->W + 1 + 7) & ~7;                    // positions per quad-row: >= one zero position, rows of whole 128-byte lines
-    const int64_t quad_bytes = (int64_t)v->H * Wq * 16;
-    if (quad_bytes >= 0x7fffffffLL) return false;
-    // output addressing of the kernel: 31-bit byte offsets inside a tile (rows) and inside a chunk (planes), for either
-    // orientation of the output strides (axis-exchanged launches swap them afterwards)
-    const int64_t max_stride = (int64_t)std::max(v->oD, v->oH) * v->oW;
-    for (int c = 0; c < quad_config_count(); ++c) {
-        if (v->tune.tile >= 0 && c != v->tune.tile) continue;
-        int th, tw, nt;
-        quad_config(c, &th, &tw, &nt);
-        if ((int64_t)th * max_stride * 4 >= 0x7fffffffLL) continue;
-        const int T[3] = {1, th, tw};
-        int L[3] = {0, 0, 0};
-        bool ok = true;
-        for (int r = 1; r < 3 && ok; ++r) {
-            double ext = 0;
-            for (int k = 1; k < 3; ++k) ext += std::fabs(m[4 * r + k]) * (T[k] - 1);
-            if (!(ext < 4096.0)) { ok = false; break; }
-            L[r] = (int)std::floor(ext) + 3 + halo2;
-        }
-        if (!ok || L[1] > march_rows_max()) continue;
-        int rows = 0;
-        const int npos = estimate_span_positions(m, th, tw, halo, L[1] + 1, &rows);
-        if (rows > march_rows_max()) continue;
-        const int nvec64 = (npos + 63) & ~63;
-        if (nvec64 > nt * march_max_it()) continue;
-        const int slot_bytes = nvec64 * 16;                   // a power-of-two-free size is fine: the ring toggles with XOR of slot_bytes...
-        // ... which needs slot 0 at offset 0 and slot 1 at offset slot_bytes: any size works
-        const int64_t bytes = std::max<int64_t>(2LL * slot_bytes, march_table_bytes());
-        if (bytes > v->lds_limit) continue;
-        plan->kind = 8; plan->cfg = c; plan->td = 4; plan->th = th; plan->tw = tw;
-        plan->lds_bytes = (int)bytes;
-        p->Lz = 2; p->Ly = std::min(L[1], march_rows_max()); p->Lx = npos; p->Lx_used = npos;
-        p->slot_floats = slot_bytes / 4;
-        break;                                    // configurations are listed in order of preference: first fit wins
-    }
-    if (plan->kind != 8) return false;
-    const int T[3] = {1, plan->th, plan->tw};
     for (int r = 0; r < 3; ++r) {
-        double neg = 0, pos = 0;
-        for (int k = 1; k < 3; ++k) {
-            const double e = m[4 * r + k] * (T[k] - 1);
-            if (e < 0) neg += e; else pos += e;
-        }
-        p->neg[r] = neg; p->pos[r] = pos;
+        for (int c = 0; c < 4; ++c) m[4 * r + c] = m4x4[4 * r + c];
+        m[4 * r + 3] = std::fma(m4x4[4 * r], (double)v->out_plane0, m4x4[4 * r + 3]);
     }
-    const double fl = std::floor(m[3]);
-    p->zoff = (int32_t)fl;
-    p->fz = (float)(m[3] - fl);
-    p->nTh = (v->oH + plan->th - 1) / plan->th;
-    p->nTw = (v->oW + plan->tw - 1) / plan->tw;
-    p->sPq = 4 * Wq;
-    p->zero_off_q = v->W * 16;
-    p->flags = (flags & VT_KEEP_OUTSIDE) | (v->tune.exp_nostore ? (1 << 21) : 0) | (v->tune.exp_noload ? (1 << 22) : 0) |
-               (v->tune.exp_nolds ? (1 << 26) : 0) | (v->tune.exp_noloop ? (1 << 27) : 0);
-    if (v->tune.quad_nt < 0 ? true : v->tune.quad_nt != 0) p->flags |= (1 << 28);
-    const int64_t inplane = (int64_t)p->nTh * p->nTw;
-    // chunk depth: every chunk pays one or two quad steps beyond its own planes (history of the first outputs, misaligned
-    // ends), so chunks are deeper than the plain kernels' -- 64 planes = 16 steps + ~1.5
-    // [measured, tools/march_ab.py, 512^3 / 1024^3 sweeps] trilinear: 24 planes where a whole layer of tiles is resident at once
-    // (512^3: 0.204 vs 0.213 ms at 76; short-lived workgroups keep the write stream compact, tools/probes/pattern_probe.hip),
-    // 64 on larger planes (1024^3: 1.70 at 64, 1.77 at 32, 1.82 at 128); cubic: 64 (two extra steps per chunk: 512^3 0.238 at
-    // whole rounds of 256, 0.266 at 24)
-    // (cubic, after chunk starts were aligned to quads -- dshift below: 512^3 0.227 ms at 64 planes, 0.233 at 128, 0.236 at 256)
-    int target_dch = (!cubic && (int64_t)v->H * v->W <= 512 * 512) ? 24 : 64;
-    const bool round_aware = false;
-    if (v->tune.dch > 0) target_dch = std::max(4, v->tune.dch);
-    int64_t nchunks = std::max<int64_t>(1, (v->oD + target_dch - 1) / target_dch);
-    // small volumes: shorter chunks until the launch has ~4 workgroups per CU, not below 8 planes per chunk
-    if (v->tune.dch <= 0)
-        nchunks = std::max(nchunks, std::min<int64_t>((4 * (int64_t)v->cu_count + inplane - 1) / inplane, (v->oD + 7) / 8));
-    // scalar byte offsets: source quads of a chunk from its first quad, output planes from its first plane (31 bits each)
-    const int64_t n_addr = std::max(((int64_t)(v->oD / 4 + 4) * quad_bytes) / 0x60000000LL + 1, ((int64_t)v->oD * max_stride * 4) / 0x60000000LL + 1);
-    nchunks = std::max<int64_t>(nchunks, n_addr);
-    const int bpc = quad_blocks_per_cu(plan->cfg, v->interp, plan->lds_bytes);
-    plan->blocks_per_cu = bpc;
-    if (round_aware)
-        nchunks = round_aware_chunks(v->oD, 4, inplane, (int64_t)v->cu_count * bpc, nchunks, 2 + halo2, 8, n_addr);
-    int dch = (int)((v->oD + nchunks - 1) / nchunks);
-    dch = (dch + 3) & ~3;
-    // chunk boundaries at c*dch + dshift: the first tap plane of every chunk but the first, d_begin + zoff - halo, is then the
-    // first plane of a quad -- a cubic chunk marches dch/4 + 1 quads instead of dch/4 + 2 (64 planes: 17 steps instead of 18)
-    const int dshift = (int)((((int64_t)halo - (int64_t)p->zoff) % 4 + 4) % 4);
-    nchunks = (v->oD > dshift) ? (v->oD - dshift + dch - 1) / dch : 1;
-    if ((int64_t)(dch + dshift) * max_stride * 4 >= 0x7fffffffLL) { plan->kind = 1; return false; }
-    p->dch = dch;
-    p->dshift = dshift;
-    p->nTd = (int)nchunks;
-    if (v->tune.blk_h > 0 && v->tune.blk_w > 0) { p->blk_h = v->tune.blk_h; p->blk_w = v->tune.blk_w; }
-    const int64_t grid = inplane * nchunks;
-    if (grid > 0x7fffffffLL) { plan->kind = 1; return false; }
-    plan->grid = (int)grid;
-    return true;
+    m[3] -= (double)v->plane0;
 }
 
-// Choose the kernel and tile shape for one matrix (host side, a few hundred flops).
-int plan_launch(vt_volume* v, const double m[12], int flags, AffineParams* p, TilePlan* plan)
+// a handle-shaped view of the same volume with axes permuted (planning only: no buffers)
+vt_volume planning_view(const vt_volume* v, int D, int H, int W, int P, int oD, int oH, int oW, bool keep_window)
 {
-    const bool cubic = is_cubic(v->interp);
-    const int64_t n_out = (int64_t)v->oD * v->oH * v->oW;
-    std::memcpy(p->m, m, sizeof(double) * 12);
-    p->sD = v->D; p->sH = v->H; p->sW = v->W; p->sP = v->P;
+    vt_volume sw;
+    sw.dev = v->dev; sw.interp = v->interp;
+    sw.D = D; sw.H = H; sw.W = W; sw.P = P;
+    sw.oD = oD; sw.oH = oH; sw.oW = oW;
+    sw.plane0 = keep_window ? v->plane0 : 0; sw.gD = keep_window ? v->gD : D; sw.out_plane0 = keep_window ? v->out_plane0 : 0;
+    sw.lds_limit = v->lds_limit; sw.cu_count = v->cu_count; sw.tune = v->tune;
+    return sw;
+}
+
+// Rotations about axis 1 ([a 0 b; 0 1 0; c 0 d]): the same problem with axes 0 and 1 exchanged is axis-0-separable.
+// A second resident copy with those axes exchanged (built once, lazily) lets the marching kernels serve it; only
+// the output addressing changes (plane stride oW, row stride oH*oW).  Whole-volume handles only (no slab offsets).
+int try_axis1_exchange(vt_volume* v, const double m[12], int flags, size_t n_out, AffineParams* p, TilePlan* plan, Orientation* ori)
+{
+    const bool ysep = !(flags & (VT_NO_ZSEP | VT_NO_MARCH | VT_FORCE_DIRECT)) && m[5] == 1.0 && m[4] == 0.0 && m[6] == 0.0 &&
+                      m[1] == 0.0 && m[9] == 0.0 && std::fabs(m[7]) < 1.0e9 &&
+                      !(m[0] == 1.0 && m[2] == 0.0 && m[8] == 0.0) &&
+                      v->plane0 == 0 && v->out_plane0 == 0 && v->gD == v->D && v->D <= 65535 && v->H <= 65535 &&
+                      (n_out >= (size_t)64 * 64 * 64 || (flags & VT_FORCE_TILED));
+    if (!ysep) return 0;
+    vt_volume sw = planning_view(v, v->H, v->D, v->W, v->P, v->oH, v->oD, v->oW, false);
+    const int pi[3] = {1, 0, 2};
+    double ms[12];
     for (int r = 0; r < 3; ++r) {
-        // Q32.32 split of the depth-axis step m[r][0] (|m| < 4096 is checked below for tiled launches)
-        const double step = m[4 * r];
-        const double fl = std::floor(step);
-        p->inc_hi[r] = (std::fabs(step) < 2.0e9) ? (int32_t)fl : 0;
-        p->inc_lo[r] = (uint32_t)std::min(4294967295.0, std::floor((step - fl) * 4294967296.0 + 0.5));
-        if ((step - fl) * 4294967296.0 + 0.5 >= 4294967296.0) { p->inc_lo[r] = 0; p->inc_hi[r] += 1; }
+        for (int c = 0; c < 3; ++c) ms[4 * r + c] = m[4 * pi[r] + pi[c]];
+        ms[4 * r + 3] = m[4 * pi[r] + 3];
     }
-    p->oD = v->oD; p->oH = v->oH; p->oW = v->oW;
-    p->ostride = (int64_t)v->oH * v->oW; p->orow = v->oW;
-    p->ord[0] = 0; p->ord[1] = 1; p->ord[2] = 2;
-    p->ia1 = march_recip(m[5]); p->ib1 = march_recip(m[6]);
-    p->flags = (flags & VT_KEEP_OUTSIDE);
-    // skirt rule src + 0.5 in [0, dim) on the global volume, expressed on resident coordinates
-    p->vlo[0] = -0.5 - (double)v->plane0;  p->vhi[0] = (double)v->gD - 0.5 - (double)v->plane0;
-    p->vlo[1] = -0.5;                      p->vhi[1] = (double)v->H - 0.5;
-    p->vlo[2] = -0.5;                      p->vhi[2] = (double)v->W - 0.5;
+    AffineParams ps;
+    std::memset(&ps, 0, sizeof(ps));
+    TilePlan plans;
+    plan_launch(&sw, ms, flags, &ps, &plans);
+    if (!is_marching(plans.kind)) return 0;
+    if (!v->d_src_t) {
+        const size_t bytes = (size_t)v->D * v->H * v->P * sizeof(float);
+        if (hipMalloc(reinterpret_cast<void**>(&v->d_src_t), bytes) != hipSuccess) {
+            (void)hipGetLastError();          // no room for a second copy: the general kernels serve this matrix
+            v->d_src_t = nullptr;
+            return 0;
+        }
+        VT_HIP(launch_relayout_swap01(v->d_src, v->d_src_t, v->D, v->H, v->P, v->stream));
+    }
+    *p = ps; *plan = plans;
+    p->ostride = v->oW; p->orow = (int64_t)v->oH * v->oW;
+    p->ord[0] = 1; p->ord[1] = 0; p->ord[2] = 2;          // original (d, h, w) = this launch's columns (1, 0, 2)
+    ori->src_plain = v->d_src_t; ori->pair_slot = &v->d_src_t_zp; ori->quad_slot = &v->d_src_t_q; ori->quad_idx = 1;
+    ori->srcD = v->H; ori->srcH = v->D;
+    return 0;
+}
 
-    plan->kind = 1; plan->cfg = -1; plan->td = plan->th = plan->tw = 0; plan->lds_bytes = 0; plan->grid = 0;
-    bool want_tiled = n_out >= 64 * 64 * 64;
-    if (flags & VT_FORCE_TILED) want_tiled = true;
-    if (flags & VT_FORCE_DIRECT) want_tiled = false;
-    for (int i = 0; i < 12; ++i)
-        if (!std::isfinite(m[i])) return fail(VT_EINVAL, "matrix entry %d is not finite", i);
-    if (!want_tiled) return 0;
-
-    const int halo2 = cubic ? 2 : 0;           // cubic taps reach one voxel further on each side
-    // axis-0-separable block form [1 0 0 tz; 0 a b ty; 0 c d tx] (rotations about axis 0, in-plane maps)
-    const bool zsep = !(flags & VT_NO_ZSEP) && m[0] == 1.0 && m[1] == 0.0 && m[2] == 0.0 && m[4] == 0.0 && m[8] == 0.0 &&
-                      std::fabs(m[3]) < 1.0e9;
-    p->zero_off = ((v->W + 3) & ~3) * 4;
-    if (zsep && !(flags & (VT_NO_MARCH | VT_NO_QUAD | VT_NO_ZPAIR)) && plan_quad(v, m, flags, p, plan)) return 0;
-    if (zsep && !(flags & VT_NO_MARCH) && (int64_t)v->H * v->P * 4 < 0x7fffffffLL) {
-        // marching kernel: pick the in-plane tile with the least staged bytes per pixel
-        const double fl = std::floor(m[3]);
-        double best = 1e300;
-        // cubic: plane-pair layout + ds_read_b64 gather (kind 5)
-        if (cubic && !(flags & VT_NO_ZPAIR) && (int64_t)v->H * (2 * (((v->W + 3) & ~3) + 4)) * 4 < 0x7fffffffLL) {
-            const double fl = std::floor(m[3]);
-            for (int c = 0; c < zpair_config_count() && plan->kind != 5; ++c) {
-                if (v->tune.tile >= 0 && c != v->tune.tile) continue;
-                int th, tw, la, nt;
-                zpair_config(c, &th, &tw, &la, &nt);
-                if (v->tune.la > 0) la = std::min(3, v->tune.la);
-                const int vec_max = nt * march_max_it();
-                const int T[3] = {1, th, tw};
-                int L[3] = {0, 0, 0};
-                bool ok = true;
-                for (int r = 1; r < 3 && ok; ++r) {
-                    double ext = 0;
-                    for (int k = 1; k < 3; ++k) ext += std::fabs(m[4 * r + k]) * (T[k] - 1);
-                    if (!(ext < 4096.0)) { ok = false; break; }
-                    L[r] = (int)std::floor(ext) + 3 + halo2;
-                }
-                if (!ok) continue;
-                L[2] = (L[2] + 1 + 1) & ~1;                      // origin aligned down by up to 1 position, even width
-                // boxes (stride padding fetched from the zero vector) vs packed spans [measured]: 512^3 sweep mean 0.292 vs
-                // 0.312 ms, 1024^3 2.25-2.33 vs 2.28-2.38 ms -> boxes; VT_MARCH_BOX=0 selects packed spans
-                bool zp_box = true;
-                if (v->tune.march_box >= 0) zp_box = v->tune.march_box != 0;
-                const int lx_used = L[2];                         // columns that hold data; the rest is stride padding
-                int best_lx = L[2];
-                double best_f = 1e300;
-                for (int pad = 0; pad <= 30; pad += 2) {         // bank-pair index = (y*Lx + x) mod 32 for ds_read_b64
-                    // [measured at 36 and 144 degrees] every 2 positions of padding cost ~3 % (LDS footprint), a
-                    // pathological stride costs 30-50 %: the model flags the pathological ones reliably
-                    if (pad > 0 && L[1] * ((L[2] + pad) / 2) > vec_max) break;     // the padded box must still be stageable
-                    const double f = gather_conflict_factor(m[6], m[10], L[2] + pad, 1) * (1.0 + 0.015 * pad);
-                    if (f < best_f - 1e-9) { best_f = f; best_lx = L[2] + pad; }
-                }
-                if (v->tune.lxpad >= 0) best_lx = L[2] + v->tune.lxpad;
-                L[2] = best_lx;
-                int slot_floats = L[1] * L[2] * 2;
-                if (!zp_box) {
-                    int rows = 0;
-                    // packed spans: vectors of 2 positions; the estimate counts 4-position vectors, so double it (loose)
-                    const int vecs = 2 * estimate_packed_vectors(m, th, tw, 1, L[1] + 1, &rows);
-                    if (rows > march_rows_max() || L[1] > march_rows_max()) continue;
-                    slot_floats = vecs * 4;
-                    if (vecs > vec_max) continue;
-                } else if (L[1] * (L[2] / 2) > vec_max) continue;
-                // planes with far more tiles than the chip keeps resident: one more pair in flight where three slots still
-                // leave three workgroups per CU ([measured] 1024^3: 2.020 -> 1.972 ms at 0 degrees, 2.221 -> 2.202 at 30;
-                // 512^3, whole layers resident: 0.258 -> 0.263, so not there)
-                if (v->tune.la <= 0 && la == 1 && 9LL * slot_floats * 4 <= 160 * 1024 &&
-                    (int64_t)((v->oH + th - 1) / th) * ((v->oW + tw - 1) / tw) > 7LL * v->cu_count)    // 640^3, 768^3: -2..-4 % with it
-                    la = 2;
-                const int64_t bytes = std::max<int64_t>((int64_t)(la + 1) * slot_floats * 4, zp_box ? 0 : march_table_bytes());
-                if (bytes > v->lds_limit) continue;
-                plan->kind = 5; plan->cfg = c; plan->td = 2; plan->th = th; plan->tw = tw;
-                plan->lds_bytes = (int)bytes;
-                p->Lz = la + 1; p->Ly = L[1]; p->Lx = L[2]; p->Lx_used = lx_used;
-                p->slot_floats = slot_floats;
-                p->flags = (flags & VT_KEEP_OUTSIDE) | (zp_box ? (1 << 20) : 0) | (v->tune.exp_nostore ? (1 << 21) : 0) |
-                           (v->tune.exp_noload ? (1 << 22) : 0) | (v->tune.exp_nolds ? (1 << 26) : 0);
-            }
-            if (plan->kind == 5) {
-                const int T[3] = {1, plan->th, plan->tw};
-                for (int r = 0; r < 3; ++r) {
-                    double neg = 0, pos = 0;
-                    for (int k = 1; k < 3; ++k) {
-                        const double e = m[4 * r + k] * (T[k] - 1);
-                        if (e < 0) neg += e; else pos += e;
-                    }
-                    p->neg[r] = neg; p->pos[r] = pos;
-                }
-                p->zoff = (int32_t)fl;
-                p->fz = (float)(m[3] - fl);
-                p->nTh = (v->oH + plan->th - 1) / plan->th;
-                p->nTw = (v->oW + plan->tw - 1) / plan->tw;
-                p->sP2 = 2 * (((v->W + 3) & ~3) + 4);
-                p->zero_off2 = 2 * ((v->W + 3) & ~3) * 4;
-                const int64_t inplane = (int64_t)p->nTh * p->nTw;
-                int target_dch = ((int64_t)v->H * v->W <= 512 * 512) ? 64 : 32;
-                if (v->tune.dch > 0) target_dch = std::max(2, v->tune.dch);
-                int64_t nchunks = std::max<int64_t>(1, (v->oD + target_dch - 1) / target_dch);
-                // small volumes: shorter chunks until the launch has ~4 workgroups per CU (a 128^3 volume has only 32
-                // in-plane tiles: 64-plane chunks would leave 3/4 of the chip idle), but not below 8 planes per chunk
-                if (v->tune.dch <= 0)
-                    nchunks = std::max(nchunks, std::min<int64_t>((4 * (int64_t)v->cu_count + inplane - 1) / inplane, (v->oD + 7) / 8));
-                const int64_t pair_bytes = (int64_t)v->H * p->sP2 * 4;
-                const int64_t n_addr = ((int64_t)(v->oD / 2 + 4) * pair_bytes) / 0x60000000LL + 1;   // 31-bit scalar offsets
-                nchunks = std::max<int64_t>(nchunks, n_addr);
-                if (v->tune.dch <= 0)
-                    nchunks = round_aware_chunks(v->oD, 2, inplane, (int64_t)v->cu_count * march_blocks_per_cu(true, plan->cfg, v->interp, plan->lds_bytes),
-                                                 nchunks, 4, 8, n_addr);
-                int dch = (int)((v->oD + nchunks - 1) / nchunks);
-                dch = (dch + 1) & ~1;
-                nchunks = (v->oD + dch - 1) / dch;
-                p->dch = dch;
-                p->nTd = (int)nchunks;
-                if (v->tune.blk_h > 0 && v->tune.blk_w > 0) { p->blk_h = v->tune.blk_h; p->blk_w = v->tune.blk_w; }
-                const int64_t grid = inplane * nchunks;
-                if (grid <= 0x7fffffffLL) { plan->grid = (int)grid; return 0; }
-                plan->kind = 1;
-            }
-        }
-        // Footprint staging: the linear kernels stage the packed row spans of the rotated tile (least traffic, least
-        // LDS).  The cubic kernels are LDS-read-bound and sensitive to bank conflicts, which the irregular row starts
-        // of the packed image make worse (measured 0.48 vs 0.39 ms at 45 degrees), so they stage the bounding box with
-        // a conflict-aware row stride.  VT_MARCH_BOX=0/1 overrides.
-        bool march_box = cubic;
-        if (v->tune.march_box >= 0) march_box = v->tune.march_box != 0;
-        for (int c = 0; c < march_config_count(); ++c) {
-            if (v->tune.tile >= 0 && c != v->tune.tile) continue;
-            int th, tw, g, la, nt;
-            march_config(c, &th, &tw, &g, &la, &nt);
-            if (v->tune.la > 0) la = v->tune.la;
-            const int vec_max = nt * march_max_it();
-            const int T[3] = {1, th, tw};
-            int L[3] = {0, 0, 0};
-            bool ok = true;
-            for (int r = 1; r < 3 && ok; ++r) {
-                double ext = 0;
-                for (int k = 1; k < 3; ++k) ext += std::fabs(m[4 * r + k]) * (T[k] - 1);
-                if (!(ext < 4096.0)) { ok = false; break; }
-                L[r] = (int)std::floor(ext) + 3 + halo2;
-            }
-            if (!ok || L[1] > march_rows_max()) continue;
-            int rows = 0;
-            const int vecs = estimate_packed_vectors(m, th, tw, cubic ? 1 : 0, L[1] + 1, &rows);
-            if (vecs > vec_max || rows > march_rows_max()) continue;
-            int slot_floats = vecs * 4;
-            int lx_used4 = 0;
-            if (march_box) {
-                // full bounding box with the row stride (in 16-byte steps) that predicts the fewest bank conflicts for
-                // this matrix' lane step (m[1][2], m[2][2])
-                L[2] = (L[2] + 3 + 3) & ~3;
-                lx_used4 = L[2];
-                int best_lx = L[2];
-                double best_f = 1e300;
-                for (int pad = 0; pad <= 28; pad += 4) {
-                    if (pad > 0 && L[1] * (L[2] + pad) / 4 > vec_max) break;
-                    const double f = gather_conflict_factor(m[6], m[10], L[2] + pad) * (1.0 + 0.015 * pad);
-                    if (f < best_f - 1e-9) { best_f = f; best_lx = L[2] + pad; }
-                }
-                L[2] = best_lx;
-                slot_floats = L[1] * L[2];
-                if (L[1] * L[2] / 4 > vec_max) continue;
-            }
-            const int ring = (la + 1) * g + halo2 + 1;
-            const int64_t bytes = std::max<int64_t>((int64_t)ring * slot_floats * 4, march_box ? 1024 : march_table_bytes());
-            if (bytes > v->lds_limit) continue;
-            const int blocks_per_cu = (int)std::min<int64_t>(8, (160 * 1024) / bytes);
-            // measured on MI355X (512^3 and 1024^3, 0..45 degrees): resident workgroups per CU matter more than
-            // lookahead depth inside one workgroup, so rank by occupancy first, then by staged bytes per pixel
-            // and (measured) a deeper ring or a smaller tile never paid off: configurations are listed in order of
-            // preference and the first that fits wins unless VT_TILE forces one
-            (void)blocks_per_cu;
-            double cost = (double)c;
-            if (cost < best) {
-                best = cost;
-                plan->kind = 4; plan->cfg = c; plan->td = g; plan->th = th; plan->tw = tw;
-                plan->lds_bytes = (int)bytes;
-                p->Lz = ring; p->Ly = std::min(L[1], march_rows_max()); p->Lx = L[2]; p->Lx_used = lx_used4 ? lx_used4 : L[2];
-                p->slot_floats = slot_floats;
-                p->flags = (flags & VT_KEEP_OUTSIDE) | (march_box ? (1 << 20) : 0) |
-                           (v->tune.exp_nostore ? (1 << 21) : 0) | (v->tune.exp_noload ? (1 << 22) : 0);
-                break;                            // first fit wins (planning is on the per-call path: keep it cheap)
-            }
-        }
-        if (plan->kind == 4) {
-            const int T[3] = {1, plan->th, plan->tw};
-            for (int r = 0; r < 3; ++r) {
-                double neg = 0, pos = 0;
-                for (int k = 1; k < 3; ++k) {
-                    const double e = m[4 * r + k] * (T[k] - 1);
-                    if (e < 0) neg += e; else pos += e;
-                }
-                p->neg[r] = neg; p->pos[r] = pos;
-            }
-            p->zoff = (int32_t)fl;
-            p->fz = (float)(m[3] - fl);
-            p->nTh = (v->oH + plan->th - 1) / plan->th;
-            p->nTw = (v->oW + plan->tw - 1) / plan->tw;
-            const int g = plan->td;
-            const int64_t inplane = (int64_t)p->nTh * p->nTw;
-            // short chunks keep the workgroups that share source rows (in-plane neighbours) at nearby planes, so the
-            // overlap of their boxes is served by the XCD's L2 instead of the fabric (measured: 1024^3 linear
-            // 3.4 ms at 342 planes per chunk, 2.1 ms at 16); the cubic kernels pay 5 planes of prologue per chunk
-            // [measured, 0 and 45 degrees] linear (packed spans): 16 planes at both 512^3 and 1024^3; cubic (boxes): 64 planes
-            // at 512^3 (0.379 vs 0.387 ms), 32 at 1024^3 (2.80 vs 2.88 ms)
-            const int target_dch = cubic ? (((int64_t)v->H * v->W <= 512 * 512) ? 64 : 32) : 16;
-            int64_t nchunks = std::max<int64_t>(1, (v->oD + target_dch - 1) / target_dch);
-            // small volumes: shorter chunks until the launch has ~4 workgroups per CU, not below 4 planes per chunk
-            nchunks = std::max(nchunks, std::min<int64_t>((4 * (int64_t)v->cu_count + inplane - 1) / inplane, (v->oD + 3) / 4));
-            // the chunk's planes are addressed with a 31-bit scalar byte offset from its first plane
-            const int64_t plane_bytes = (int64_t)v->H * v->P * 4;
-            const int64_t n_addr = ((int64_t)v->oD * plane_bytes) / 0x60000000LL + 1;
-            nchunks = std::max<int64_t>(nchunks, n_addr);
-            // (no round-aware chunk count here: [measured] the linear kernel loses more L2 sharing with deeper chunks than
-            // it gains from whole rounds -- 512^3 0.250 vs 0.220 ms, 640^3 0.442 vs 0.419)
-            if (v->tune.dch > 0) nchunks = std::max<int64_t>(1, (v->oD + v->tune.dch - 1) / v->tune.dch);
-            int dch = (int)((v->oD + nchunks - 1) / nchunks);
-            dch = ((dch + g - 1) / g) * g;
-            nchunks = (v->oD + dch - 1) / dch;
-            p->dch = dch;
-            p->nTd = (int)nchunks;
-            if (v->tune.blk_h > 0 && v->tune.blk_w > 0) { p->blk_h = v->tune.blk_h; p->blk_w = v->tune.blk_w; }
-            const int64_t grid = inplane * nchunks;
-            if (grid <= 0x7fffffffLL) { plan->grid = (int)grid; return 0; }
-            plan->kind = 1;
-        }
-    }
-    double best_cost = 1e300, box_bpv = 1e300;
-    for (int c = 0; c < tile_config_count(); ++c) {
-        if (v->tune.tile >= 0 && c != v->tune.tile) continue;
-        int T[3];
-        tile_config(c, &T[0], &T[1], &T[2]);
-        int L[3];
-        bool ok = true;
-        for (int r = 0; r < 3 && ok; ++r) {
-            double ext = 0;
-            for (int k = 0; k < 3; ++k) ext += std::fabs(m[4 * r + k]) * (T[k] - 1);
-            if (!(ext < 4096.0)) { ok = false; break; }
-            L[r] = (int)std::floor(ext) + 3 + halo2;       // floor(hi)-floor(lo) <= floor(ext)+1, +1 upper tap, +1 slack
-        }
-        if (ok && zsep) L[0] = T[0] + 1 + halo2;           // exactly the planes d0+zoff-halo .. d0+TD+zoff+halo
-        if (!ok) continue;
-        L[2] = (L[2] + 3 + 3) & ~3;                        // origin aligned down by up to 3, stride multiple of 4
-        const int64_t bytes = (int64_t)L[0] * L[1] * L[2] * 4;
-        if (bytes > v->lds_limit) continue;
-        const int blocks_per_cu = (int)std::min<int64_t>(8, (160 * 1024) / bytes);
-        const double vox = (double)T[0] * T[1] * T[2];
-        // staged bytes per output voxel, penalised when fewer than 3 workgroups fit a CU (no overlap of
-        // one workgroup's staging with another's gather)
-        double cost = (double)bytes / vox * (blocks_per_cu >= 3 ? 1.0 : (blocks_per_cu == 2 ? 1.25 : 2.0));
-        if (cost < best_cost) {
-            best_cost = cost;
-            box_bpv = (double)bytes / vox;
-            plan->kind = zsep ? 3 : 2; plan->cfg = c; plan->td = T[0]; plan->th = T[1]; plan->tw = T[2];
-            plan->lds_bytes = (int)bytes;
-            p->Lz = L[0]; p->Ly = L[1]; p->Lx = L[2];
-        }
-    }
-    // general matrices: packed 3-D footprints (kind 6) when the linear part is invertible
-    // Bounding boxes are cheaper to address (no row table), so the packed form must stage clearly less to win:
-    // measured cross-over at ~0.6x of the box bytes per voxel for trilinear (512^3).  Cubic: since both kernels gather
-    // with 8-byte reads the boxes win at every size ([measured] rotation (25,-40,70): 250^3 0.177 vs 0.198 ms, 384^3 0.563 vs
-    // 0.604, 512^3 1.295 vs 1.328), so the packed form is only planned for trilinear (or when forced).
-    if (!zsep && !(flags & VT_NO_PACKED) && (!cubic || (flags & VT_FORCE_PACKED))) {
-        const double A[9] = {m[0], m[1], m[2], m[4], m[5], m[6], m[8], m[9], m[10]};
-        const double det = A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6]) + A[2] * (A[3] * A[7] - A[4] * A[6]);
-        double amax = 0;
-        for (double a : A) amax = std::max(amax, std::fabs(a));
-        if (std::fabs(det) > 1e-6 * amax * amax * amax && amax < 64.0) {
-            const double id = 1.0 / det;
-            const double inv[9] = {(A[4] * A[8] - A[5] * A[7]) * id, (A[2] * A[7] - A[1] * A[8]) * id, (A[1] * A[5] - A[2] * A[4]) * id,
-                                   (A[5] * A[6] - A[3] * A[8]) * id, (A[0] * A[8] - A[2] * A[6]) * id, (A[2] * A[3] - A[0] * A[5]) * id,
-                                   (A[3] * A[7] - A[4] * A[6]) * id, (A[1] * A[6] - A[0] * A[7]) * id, (A[0] * A[4] - A[1] * A[3]) * id};
-            double best = 1e300, best_bpv = 1e300;
-            TilePlan pk = *plan;
-            AffineParams pp = *p;
-            pk.kind = 0;
-            for (int c = 0; c < packed_config_count(); ++c) {
-                if (v->tune.tile >= 0 && c != v->tune.tile) continue;
-                int T[3];
-                packed_config(c, &T[0], &T[1], &T[2]);
-                // too few tiles to amortise the per-workgroup set-up (see `enough` below): do not even plan it -- the span
-                // summation below is the most expensive part of the host-side planning (~20 us)
-                const int64_t tiles_c = (int64_t)((v->oD + T[0] - 1) / T[0]) * ((v->oH + T[1] - 1) / T[1]) * ((v->oW + T[2] - 1) / T[2]);
-                if (!(flags & VT_FORCE_PACKED) && tiles_c < 6 * (int64_t)v->cu_count * (cubic ? 2 : 3)) continue;
-                PackGeom g;
-                int L[3];
-                bool ok = true;
-                double neg[3], pos[3];
-                for (int r = 0; r < 3 && ok; ++r) {
-                    double ext = 0;
-                    neg[r] = pos[r] = 0;
-                    for (int k = 0; k < 3; ++k) {
-                        const double e = m[4 * r + k] * (T[k] - 1);
-                        ext += std::fabs(e);
-                        if (e < 0) neg[r] += e; else pos[r] += e;
-                    }
-                    if (!(ext < 1000.0)) { ok = false; break; }
-                    g.ext[r] = ext;
-                    L[r] = (int)std::floor(ext) + 3 + halo2;
-                }
-                if (!ok) continue;
-                L[2] = (L[2] + 3 + 3) & ~3;
-                const int rows = L[0] * L[1];
-                if (rows > packed_rows_max() || L[2] > 4000) continue;
-                for (int i = 0; i < 9; ++i) g.inv[i] = inv[i];
-                for (int cc = 0; cc < 3; ++cc) g.cst[cc] = inv[3 * cc] * neg[0] + inv[3 * cc + 1] * neg[1] + inv[3 * cc + 2] * neg[2];
-                g.T[0] = T[0]; g.T[1] = T[1]; g.T[2] = T[2];
-                g.halo = cubic ? 1 : 0;
-                g.Lxbox = L[2];
-                g.Lybox = L[1];
-                int nvec = 0;
-                for (int row = 0; row < rows; ++row) {
-                    int mn, mx;
-                    if (packed_row_span(g, row / L[1], row % L[1], &mn, &mx)) nvec += ((mx - (mn & ~3)) >> 2) + 1;
-                }
-                const int cap_vec = nvec + rows / 16 + 8;                 // margin for host/device rounding differences
-                if (cap_vec > packed_vectors_max()) continue;
-                const int table_floats = (2 * rows + 8 + 3) & ~3;
-                const int64_t bytes = ((int64_t)table_floats + (int64_t)cap_vec * 4) * 4;
-                if (bytes > v->lds_limit) continue;
-                const int blocks_per_cu = (int)std::min<int64_t>(cubic ? 2 : 3, (160 * 1024) / bytes);   // VGPR-limited occupancy
-                const double vox = (double)T[0] * T[1] * T[2];
-                const double cost = (double)bytes / vox * (blocks_per_cu >= 3 ? 1.0 : (blocks_per_cu == 2 ? 1.2 : 2.0));
-                if (cost < best) {
-                    best = cost;
-                    best_bpv = (double)bytes / vox;
-                    pk.kind = 6; pk.cfg = c; pk.td = T[0]; pk.th = T[1]; pk.tw = T[2];
-                    pk.lds_bytes = (int)bytes;
-                    pp.Lz = L[0]; pp.Ly = L[1]; pp.Lx = cap_vec * 4;
-                    pp.slot_floats = table_floats;
-                    for (int r = 0; r < 3; ++r) { pp.neg[r] = neg[r]; pp.pos[r] = pos[r]; }
-                    pk.geo = g;
-                    pk.blocks_per_cu = blocks_per_cu;
-                }
-            }
-            const bool forced = (flags & VT_FORCE_PACKED) != 0;
-            // every persistent workgroup pays ~20 us to build its span table and staging descriptors: worth it only when it
-            // then walks several tiles (measured: boxes win up to 250^3, on par at 320^3, packed 1.5x ahead at 512^3)
-            const int64_t pk_tiles = (int64_t)((v->oD + pk.td - 1) / std::max(1, pk.td)) * ((v->oH + pk.th - 1) / std::max(1, pk.th)) *
-                                     ((v->oW + pk.tw - 1) / std::max(1, pk.tw));
-            const bool enough = pk.kind == 6 && pk_tiles >= 6 * (int64_t)v->cu_count * std::max(1, pk.blocks_per_cu);
-            if (pk.kind == 6 && (plan->kind < 2 || forced || (enough && best_bpv < (cubic ? 0.5 : 0.6) * box_bpv))) {
-                *plan = pk;
-                *p = pp;
-                const int T[3] = {plan->td, plan->th, plan->tw};
-                p->nTd = (v->oD + T[0] - 1) / T[0];
-                p->nTh = (v->oH + T[1] - 1) / T[1];
-                p->nTw = (v->oW + T[2] - 1) / T[2];
-                const int64_t ntiles = (int64_t)p->nTd * p->nTh * p->nTw;
-                if (ntiles <= 0x7fffffffLL) {
-                    // persistent workgroups: as many as stay resident, a multiple of 8 (one share per XCD)
-                    if (v->tune.plain_tile_order) p->flags |= (1 << 23);
-                    int64_t nwg = std::min<int64_t>(ntiles, (int64_t)v->cu_count * std::max(1, plan->blocks_per_cu));
-                    nwg = std::max<int64_t>(8, (nwg + 7) / 8 * 8);
-                    plan->grid = (int)nwg;
-                    return 0;
-                }
-                plan->kind = 1;
-                return 0;
-            }
-        }
-    }
-    if (plan->kind < 2) return 0;              // footprint does not fit LDS: direct gather
-    if (zsep) {
-        const double fl = std::floor(m[3]);
-        p->zoff = (int32_t)fl;
-        p->fz = (float)(m[3] - fl);
-    }
-
-    const int T[3] = {plan->td, plan->th, plan->tw};
+// Rotations about axis 2 ([a b 0; c d 0; 0 0 1]): axis-0-separable after exchanging axes 0 and 2.  The marching kernels
+// run on the exchanged copy and produce an exchanged result, which one transpose pass (8 B/voxel) turns back.
+// Cubic only: trilinear rotations about axis 2 are the bounding-box kernel's best case (x stays contiguous: 0.34 ms at
+// 512^3, faster than marching 0.25 + transposing 0.2); VT_FORCE_XSWAP (diagnostic) takes the exchange path regardless.
+int try_axis2_exchange(vt_volume* v, const double m[12], int flags, size_t n_out, AffineParams* p, TilePlan* plan, Orientation* ori)
+{
+    const bool xsep = !(flags & (VT_NO_ZSEP | VT_NO_MARCH | VT_FORCE_DIRECT | VT_KEEP_OUTSIDE)) &&
+                      (is_cubic(v->interp) || (flags & VT_FORCE_XSWAP)) &&
+                      m[10] == 1.0 && m[8] == 0.0 && m[9] == 0.0 && m[2] == 0.0 && m[6] == 0.0 && std::fabs(m[11]) < 1.0e9 &&
+                      !(m[0] == 1.0 && m[1] == 0.0 && m[4] == 0.0) && !(m[5] == 1.0 && m[1] == 0.0 && m[4] == 0.0) &&
+                      v->plane0 == 0 && v->out_plane0 == 0 && v->gD == v->D && v->H <= 65535 && v->oH <= 65535 &&
+                      (n_out >= (size_t)64 * 64 * 64 || (flags & VT_FORCE_TILED));
+    if (!xsep) return 0;
+    vt_volume sw = planning_view(v, v->W, v->H, v->D, resident_pitch(v->D), v->oW, v->oH, v->oD, false);
+    const int pi[3] = {2, 1, 0};
+    double ms[12];
     for (int r = 0; r < 3; ++r) {
-        double neg = 0, pos = 0;
-        for (int k = 0; k < 3; ++k) {
-            const double e = m[4 * r + k] * (T[k] - 1);
-            if (e < 0) neg += e; else pos += e;
-        }
-        p->neg[r] = neg; p->pos[r] = pos;
+        for (int c = 0; c < 3; ++c) ms[4 * r + c] = m[4 * pi[r] + pi[c]];
+        ms[4 * r + 3] = m[4 * pi[r] + 3];
     }
-    p->nTd = (v->oD + T[0] - 1) / T[0];
-    p->nTh = (v->oH + T[1] - 1) / T[1];
-    p->nTw = (v->oW + T[2] - 1) / T[2];
-    const int64_t grid = (int64_t)p->nTd * p->nTh * p->nTw;
-    if (grid > 0x7fffffffLL) { plan->kind = 1; return 0; }
-    plan->grid = (int)grid;
+    AffineParams ps;
+    std::memset(&ps, 0, sizeof(ps));
+    TilePlan plans;
+    plan_launch(&sw, ms, flags, &ps, &plans);
+    if (!is_marching(plans.kind)) return 0;
+    if (v->tmp_x_elems < n_out) {
+        if (v->d_tmp_x) { VT_HIP(hipFree(v->d_tmp_x)); v->d_tmp_x = nullptr; v->tmp_x_elems = 0; }
+        if (hipMalloc(reinterpret_cast<void**>(&v->d_tmp_x), n_out * sizeof(float)) != hipSuccess) {
+            (void)hipGetLastError();          // no room: the general kernels serve this matrix
+            v->d_tmp_x = nullptr;
+            return 0;
+        }
+        v->tmp_x_elems = n_out;
+    }
+    if (!v->d_src_x) {
+        v->Px = sw.P;
+        const size_t bytes = (size_t)v->W * v->H * v->Px * sizeof(float);
+        if (hipMalloc(reinterpret_cast<void**>(&v->d_src_x), bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            v->d_src_x = nullptr;
+            return 0;
+        }
+        VT_HIP(hipMemsetAsync(v->d_src_x, 0, bytes, v->stream));          // pad columns must be zero
+        VT_HIP(launch_transpose02(v->d_src, v->d_src_x, v->D, v->H, v->W, (int64_t)v->H * v->P, v->P,
+                                  (int64_t)v->H * v->Px, v->Px, v->stream));
+    }
+    *p = ps; *plan = plans;
+    p->ord[0] = 2; p->ord[1] = 1; p->ord[2] = 0;          // original (d, h, w) = this launch's columns (2, 1, 0)
+    ori->src_plain = v->d_src_x; ori->pair_slot = &v->d_src_x_zp; ori->quad_slot = &v->d_src_x_q; ori->quad_idx = 3;
+    ori->srcD = v->W; ori->srcH = v->H; ori->pair_W = v->D; ori->pair_P = v->Px;
+    ori->xswap = true;
+    return 0;
+}
+
+// In-plane maps closer to a quarter turn than to the identity (|m12| > |m11|: rotations about axis 0 by 45..135 and
+// 225..315 degrees): sampled from an in-plane TRANSPOSED resident copy the same map has its rows 1 and 2 exchanged and
+// falls into the 0..45 degree class, whose footprints are wide in x (long staged rows, lanes walk along LDS rows
+// instead of down a column).  Only the source side changes; the output is written as usual.
+int try_inplane_transposed(vt_volume* v, const double m[12], int flags, size_t n_out, AffineParams* p, TilePlan* plan, Orientation* ori)
+{
+    const bool zsep_m = m[0] == 1.0 && m[1] == 0.0 && m[2] == 0.0 && m[4] == 0.0 && m[8] == 0.0 && std::fabs(m[3]) < 1.0e9;
+    const bool rsep = zsep_m && !(flags & (VT_NO_ZSEP | VT_NO_MARCH | VT_FORCE_DIRECT | VT_NO_RSWAP)) &&
+                      std::fabs(m[6]) > std::fabs(m[5]) && std::fabs(m[9]) > std::fabs(m[10]) && v->D <= 65535 &&
+                      (n_out >= (size_t)64 * 64 * 64 || (flags & VT_FORCE_TILED));
+    if (!rsep) return 0;
+    vt_volume sw = planning_view(v, v->D, v->W, v->H, resident_pitch(v->H), v->oD, v->oH, v->oW, true);
+    double ms[12];
+    for (int c = 0; c < 4; ++c) { ms[c] = m[c]; ms[4 + c] = m[8 + c]; ms[8 + c] = m[4 + c]; }
+    AffineParams ps;
+    std::memset(&ps, 0, sizeof(ps));
+    TilePlan plans;
+    plan_launch(&sw, ms, flags, &ps, &plans);
+    if (!is_marching(plans.kind)) return 0;
+    if (!v->d_src_r) {
+        v->Pr = sw.P;
+        const size_t bytes = (size_t)v->D * v->W * v->Pr * sizeof(float);
+        if (hipMalloc(reinterpret_cast<void**>(&v->d_src_r), bytes) != hipSuccess) {
+            (void)hipGetLastError();          // no room for another copy: the plain layout serves this matrix
+            v->d_src_r = nullptr;
+            return 0;
+        }
+        VT_HIP(hipMemsetAsync(v->d_src_r, 0, bytes, v->stream));          // pad columns must be zero
+        // dst[x][z][y] in (k, j, i) terms: element (i = y, j = z, k = x) -> (k = x, j = z, i = y)
+        VT_HIP(launch_transpose02(v->d_src, v->d_src_r, v->H, v->D, v->W, v->P, (int64_t)v->H * v->P,
+                                  v->Pr, (int64_t)v->W * v->Pr, v->stream));
+    }
+    *p = ps; *plan = plans;
+    ori->src_plain = v->d_src_r; ori->pair_slot = &v->d_src_r_zp; ori->quad_slot = &v->d_src_r_q; ori->quad_idx = 2;
+    ori->srcD = v->D; ori->srcH = v->W; ori->pair_W = v->H; ori->pair_P = v->Pr;
+    if (!v->tune.rswap_wfast) p->flags |= (1 << 24);          // h-fastest tile order on the transposed copy
+    return 0;
+}
+
+void note_launch(vt_volume* v, int kind, const TilePlan& plan, const AffineParams& p, size_t n_out)
+{
+    v->last_kernel = kind;
+    const bool tiled = kind >= 2;
+    v->last_tile[0] = tiled ? plan.td : 0; v->last_tile[1] = tiled ? plan.th : 0; v->last_tile[2] = tiled ? plan.tw : 0;
+    v->last_lds[0] = tiled ? p.Lz : 0; v->last_lds[1] = tiled ? p.Ly : 0; v->last_lds[2] = tiled ? p.Lx : 0;
+    v->last_lds_bytes = tiled ? plan.lds_bytes : 0;
+    v->last_grid = tiled ? plan.grid : (int)((n_out + 255) / 256);
+}
+
+// build the secondary resident copy a plan needs (once), then launch the plan's kernel into d_out
+int launch_planned(vt_volume* v, const TilePlan& plan, const AffineParams& p, const Orientation& ori, float* d_out, size_t n_out)
+{
+    if (plan.kind == 8) {
+        if (!*ori.quad_slot) {
+            // the plane-quad copy of the (prefiltered) resident source; positions beyond the row's width stay zero
+            const size_t qbytes = (size_t)((ori.srcD + 3) / 4) * ori.srcH * p.sPq * sizeof(float);
+            VT_HIP(hipMalloc(reinterpret_cast<void**>(ori.quad_slot), qbytes));
+            v->quad_bytes[ori.quad_idx] = qbytes;
+            VT_HIP(hipMemsetAsync(*ori.quad_slot, 0, qbytes, v->stream));
+            VT_HIP(launch_relayout_zquad(ori.src_plain, *ori.quad_slot, ori.srcD, ori.srcH, ori.pair_W, ori.pair_P, p.sPq, v->stream));
+        }
+        VT_HIP(launch_affine_quad(plan.cfg, v->interp, *ori.quad_slot, d_out, p, plan.grid, plan.lds_bytes, v->stream));
+    } else if (plan.kind == 5) {
+        if (!*ori.pair_slot) {
+            // the plane-pair copy of the (prefiltered) resident source
+            v->P2 = p.sP2;
+            const size_t zbytes = (size_t)((ori.srcD + 1) / 2) * ori.srcH * v->P2 * sizeof(float);
+            VT_HIP(hipMalloc(reinterpret_cast<void**>(ori.pair_slot), zbytes));
+            VT_HIP(hipMemsetAsync(*ori.pair_slot, 0, zbytes, v->stream));
+            VT_HIP(launch_relayout_zpair(ori.src_plain, *ori.pair_slot, ori.srcD, ori.srcH, ori.pair_W, ori.pair_P, v->P2, v->stream));
+        }
+        VT_HIP(launch_affine_zpair(plan.cfg, v->interp, *ori.pair_slot, d_out, p, plan.grid, plan.lds_bytes, v->stream));
+    } else if (plan.kind == 6) {
+        VT_HIP(launch_affine_packed(plan.cfg, v->interp, v->d_src, d_out, v->d_zeros, p, plan.geo, plan.grid, plan.lds_bytes, v->stream));
+    } else if (plan.kind == 4) {
+        VT_HIP(launch_affine_march(plan.cfg, v->interp, ori.src_plain, d_out, p, plan.grid, plan.lds_bytes, v->stream));
+    } else if (plan.kind >= 2) {
+        VT_HIP(launch_affine_tiled(plan.cfg, v->interp, plan.kind == 3, v->d_src, d_out, v->d_zeros, p, plan.grid, plan.lds_bytes, v->stream));
+    } else {
+        VT_HIP(launch_affine_direct(v->interp, v->d_src, d_out, p, v->stream));
+    }
+    note_launch(v, plan.kind >= 2 ? plan.kind : 1, plan, p, n_out);
+    return 0;
+}
+
+// device staging buffer for a host `out` (recycled through the per-device cache)
+int host_output_buffer(vt_volume* v, size_t n_elems, float** d_out)
+{
+    if (v->scratch_elems < n_elems) {
+        if (v->d_scratch_out) { cached_free(v->dev, v->d_scratch_out, v->scratch_elems * sizeof(float)); v->d_scratch_out = nullptr; v->scratch_elems = 0; }
+        VT_HIP(cached_malloc(v->dev, reinterpret_cast<void**>(&v->d_scratch_out), n_elems * sizeof(float)));
+        v->scratch_elems = n_elems;
+    }
+    *d_out = v->d_scratch_out;
     return 0;
 }
 
@@ -1079,258 +577,42 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
     if (!v || !m4x4 || !out) return fail(VT_EINVAL, "NULL argument");
     int rc = use_device(v->dev);
     if (rc) return rc;
-
-    // fold the output-plane offset and the resident-window offset into the translation column:
-    // src_resident = M . (d + out_plane0, h, w, 1) - (plane0, 0, 0)
+    (void)hipGetLastError();                      // a stale sticky error of an unrelated call must not fail this launch's check
     double m[12];
-    for (int r = 0; r < 3; ++r) {
-        for (int c = 0; c < 4; ++c) m[4 * r + c] = m4x4[4 * r + c];
-        m[4 * r + 3] = std::fma(m4x4[4 * r], (double)v->out_plane0, m4x4[4 * r + 3]);
-    }
-    m[3] -= (double)v->plane0;
+    fold_matrix(v, m4x4, m);
+    for (int i = 0; i < 12; ++i)
+        if (!std::isfinite(m[i])) return fail(VT_EINVAL, "matrix entry %d is not finite", i);
 
     AffineParams p;
     std::memset(&p, 0, sizeof(p));
     TilePlan plan;
     plan.kind = 0;
-    // Rotations about axis 1 ([a 0 b; 0 1 0; c 0 d]): the same problem with axes 0 and 1 exchanged is axis-0-separable.
-    // A second resident copy with those axes exchanged (built once, lazily) lets the marching kernels serve it; only
-    // the output addressing changes (plane stride oW, row stride oH*oW).  Whole-volume handles only (no slab offsets).
-    const float* src_plain = v->d_src;
-    float** pair_slot = &v->d_src_zp;
-    float** quad_slot = &v->d_src_q;
-    int quad_idx = 0;
-    int srcD = v->D, srcH = v->H;
+    Orientation ori;
+    ori.src_plain = v->d_src; ori.pair_slot = &v->d_src_zp; ori.quad_slot = &v->d_src_q; ori.quad_idx = 0;
+    ori.srcD = v->D; ori.srcH = v->H; ori.pair_W = v->W; ori.pair_P = v->P;
     const size_t n_out = (size_t)v->oD * v->oH * v->oW;
-    const bool ysep = !(flags & (VT_NO_ZSEP | VT_NO_MARCH | VT_FORCE_DIRECT)) && m[5] == 1.0 && m[4] == 0.0 && m[6] == 0.0 &&
-                      m[1] == 0.0 && m[9] == 0.0 && std::fabs(m[7]) < 1.0e9 &&
-                      !(m[0] == 1.0 && m[2] == 0.0 && m[8] == 0.0) &&
-                      v->plane0 == 0 && v->out_plane0 == 0 && v->gD == v->D && v->D <= 65535 && v->H <= 65535 &&
-                      (n_out >= (size_t)64 * 64 * 64 || (flags & VT_FORCE_TILED));
-    if (ysep) {
-        vt_volume sw;
-        sw.dev = v->dev; sw.interp = v->interp;
-        sw.D = v->H; sw.H = v->D; sw.W = v->W; sw.P = v->P;
-        sw.oD = v->oH; sw.oH = v->oD; sw.oW = v->oW;
-        sw.plane0 = 0; sw.gD = v->H; sw.out_plane0 = 0;
-        sw.lds_limit = v->lds_limit; sw.cu_count = v->cu_count; sw.tune = v->tune;
-        const int pi[3] = {1, 0, 2};
-        double ms[12];
-        for (int r = 0; r < 3; ++r) {
-            for (int c = 0; c < 3; ++c) ms[4 * r + c] = m[4 * pi[r] + pi[c]];
-            ms[4 * r + 3] = m[4 * pi[r] + 3];
-        }
-        AffineParams ps;
-        std::memset(&ps, 0, sizeof(ps));
-        TilePlan plans;
-        rc = plan_launch(&sw, ms, flags, &ps, &plans);
-        if (rc) return rc;
-        if ((plans.kind == 4 || plans.kind == 5 || plans.kind == 8) && !v->d_src_t) {
-            const size_t bytes = (size_t)v->D * v->H * v->P * sizeof(float);
-            if (hipMalloc(reinterpret_cast<void**>(&v->d_src_t), bytes) != hipSuccess) {
-                (void)hipGetLastError();          // no room for a second copy: the general kernels serve this matrix
-                v->d_src_t = nullptr;
-                plans.kind = 0;
-            } else {
-                VT_HIP(launch_relayout_swap01(v->d_src, v->d_src_t, v->D, v->H, v->P, v->stream));
-            }
-        }
-        if (plans.kind == 4 || plans.kind == 5 || plans.kind == 8) {
-            quad_slot = &v->d_src_t_q; quad_idx = 1;
-            p = ps; plan = plans;
-            p.ostride = v->oW; p.orow = (int64_t)v->oH * v->oW;
-            p.ord[0] = 1; p.ord[1] = 0; p.ord[2] = 2;          // original (d, h, w) = this launch's columns (1, 0, 2)
-            src_plain = v->d_src_t; pair_slot = &v->d_src_t_zp;
-            srcD = v->H; srcH = v->D;
-        }
-    }
-    // Rotations about axis 2 ([a b 0; c d 0; 0 0 1]): axis-0-separable after exchanging axes 0 and 2.  The marching kernels
-    // run on the exchanged copy and produce an exchanged result, which one transpose pass (8 B/voxel) turns back.
-    bool xswap = false;
-    int pair_W = v->W, pair_P = v->P;             // row geometry of the plain copy the pair copy is built from
-    // Cubic only: trilinear rotations about axis 2 are the bounding-box kernel's best case (x stays contiguous: 0.34 ms at
-    // 512^3, faster than marching 0.25 + transposing 0.2); VT_FORCE_XSWAP (diagnostic) takes the exchange path regardless.
-    const bool xsep = plan.kind == 0 && !(flags & (VT_NO_ZSEP | VT_NO_MARCH | VT_FORCE_DIRECT | VT_KEEP_OUTSIDE)) &&
-                      (is_cubic(v->interp) || (flags & VT_FORCE_XSWAP)) &&
-                      m[10] == 1.0 && m[8] == 0.0 && m[9] == 0.0 && m[2] == 0.0 && m[6] == 0.0 && std::fabs(m[11]) < 1.0e9 &&
-                      !(m[0] == 1.0 && m[1] == 0.0 && m[4] == 0.0) && !(m[5] == 1.0 && m[1] == 0.0 && m[4] == 0.0) &&
-                      v->plane0 == 0 && v->out_plane0 == 0 && v->gD == v->D && v->H <= 65535 && v->oH <= 65535 &&
-                      (n_out >= (size_t)64 * 64 * 64 || (flags & VT_FORCE_TILED));
-    if (xsep) {
-        vt_volume sw;
-        sw.dev = v->dev; sw.interp = v->interp;
-        sw.D = v->W; sw.H = v->H; sw.W = v->D; sw.P = resident_pitch(v->D);
-        sw.oD = v->oW; sw.oH = v->oH; sw.oW = v->oD;
-        sw.plane0 = 0; sw.gD = v->W; sw.out_plane0 = 0;
-        sw.lds_limit = v->lds_limit; sw.cu_count = v->cu_count; sw.tune = v->tune;
-        const int pi[3] = {2, 1, 0};
-        double ms[12];
-        for (int r = 0; r < 3; ++r) {
-            for (int c = 0; c < 3; ++c) ms[4 * r + c] = m[4 * pi[r] + pi[c]];
-            ms[4 * r + 3] = m[4 * pi[r] + 3];
-        }
-        AffineParams ps;
-        std::memset(&ps, 0, sizeof(ps));
-        TilePlan plans;
-        rc = plan_launch(&sw, ms, flags, &ps, &plans);
-        if (rc) return rc;
-        if ((plans.kind == 4 || plans.kind == 5 || plans.kind == 8) && v->tmp_x_elems < n_out) {
-            if (v->d_tmp_x) { VT_HIP(hipFree(v->d_tmp_x)); v->d_tmp_x = nullptr; v->tmp_x_elems = 0; }
-            if (hipMalloc(reinterpret_cast<void**>(&v->d_tmp_x), n_out * sizeof(float)) != hipSuccess) {
-                (void)hipGetLastError();          // no room: the general kernels serve this matrix
-                v->d_tmp_x = nullptr;
-                plans.kind = 0;
-            } else v->tmp_x_elems = n_out;
-        }
-        if ((plans.kind == 4 || plans.kind == 5 || plans.kind == 8) && !v->d_src_x) {
-            v->Px = sw.P;
-            const size_t bytes = (size_t)v->W * v->H * v->Px * sizeof(float);
-            if (hipMalloc(reinterpret_cast<void**>(&v->d_src_x), bytes) != hipSuccess) {
-                (void)hipGetLastError();
-                v->d_src_x = nullptr;
-                plans.kind = 0;
-            } else {
-                VT_HIP(hipMemsetAsync(v->d_src_x, 0, bytes, v->stream));          // pad columns must be zero
-                VT_HIP(launch_transpose02(v->d_src, v->d_src_x, v->D, v->H, v->W, (int64_t)v->H * v->P, v->P,
-                                          (int64_t)v->H * v->Px, v->Px, v->stream));
-            }
-        }
-        if (plans.kind == 4 || plans.kind == 5 || plans.kind == 8) {
-            quad_slot = &v->d_src_x_q; quad_idx = 3;
-            p = ps; plan = plans;
-            src_plain = v->d_src_x; pair_slot = &v->d_src_x_zp;
-            srcD = v->W; srcH = v->H; pair_W = v->D; pair_P = v->Px;
-            p.ord[0] = 2; p.ord[1] = 1; p.ord[2] = 0;          // original (d, h, w) = this launch's columns (2, 1, 0)
-            xswap = true;
-        }
-    }
-    // In-plane maps closer to a quarter turn than to the identity (|m12| > |m11|: rotations about axis 0 by 45..135 and
-    // 225..315 degrees): sampled from an in-plane TRANSPOSED resident copy the same map has its rows 1 and 2 exchanged and
-    // falls into the 0..45 degree class, whose footprints are wide in x (long staged rows, lanes walk along LDS rows
-    // instead of down a column).  Only the source side changes; the output is written as usual.
-    const bool zsep_m = m[0] == 1.0 && m[1] == 0.0 && m[2] == 0.0 && m[4] == 0.0 && m[8] == 0.0 && std::fabs(m[3]) < 1.0e9;
-    const bool rsep = plan.kind == 0 && zsep_m && !(flags & (VT_NO_ZSEP | VT_NO_MARCH | VT_FORCE_DIRECT | VT_NO_RSWAP)) &&
-                      std::fabs(m[6]) > std::fabs(m[5]) && std::fabs(m[9]) > std::fabs(m[10]) && v->D <= 65535 &&
-                      (n_out >= (size_t)64 * 64 * 64 || (flags & VT_FORCE_TILED));
-    if (rsep) {
-        vt_volume sw;
-        sw.dev = v->dev; sw.interp = v->interp;
-        sw.D = v->D; sw.H = v->W; sw.W = v->H; sw.P = resident_pitch(v->H);
-        sw.oD = v->oD; sw.oH = v->oH; sw.oW = v->oW;
-        sw.plane0 = v->plane0; sw.gD = v->gD; sw.out_plane0 = v->out_plane0;
-        sw.lds_limit = v->lds_limit; sw.cu_count = v->cu_count; sw.tune = v->tune;
-        double ms[12];
-        for (int c = 0; c < 4; ++c) { ms[c] = m[c]; ms[4 + c] = m[8 + c]; ms[8 + c] = m[4 + c]; }
-        AffineParams ps;
-        std::memset(&ps, 0, sizeof(ps));
-        TilePlan plans;
-        rc = plan_launch(&sw, ms, flags, &ps, &plans);
-        if (rc) return rc;
-        if ((plans.kind == 4 || plans.kind == 5 || plans.kind == 8) && !v->d_src_r) {
-            v->Pr = sw.P;
-            const size_t bytes = (size_t)v->D * v->W * v->Pr * sizeof(float);
-            if (hipMalloc(reinterpret_cast<void**>(&v->d_src_r), bytes) != hipSuccess) {
-                (void)hipGetLastError();          // no room for another copy: the plain layout serves this matrix
-                v->d_src_r = nullptr;
-                plans.kind = 0;
-            } else {
-                VT_HIP(hipMemsetAsync(v->d_src_r, 0, bytes, v->stream));          // pad columns must be zero
-                // dst[x][z][y] in (k, j, i) terms: element (i = y, j = z, k = x) -> (k = x, j = z, i = y)
-                VT_HIP(launch_transpose02(v->d_src, v->d_src_r, v->H, v->D, v->W, v->P, (int64_t)v->H * v->P,
-                                          v->Pr, (int64_t)v->W * v->Pr, v->stream));
-            }
-        }
-        if (plans.kind == 4 || plans.kind == 5 || plans.kind == 8) {
-            quad_slot = &v->d_src_r_q; quad_idx = 2;
-            p = ps; plan = plans;
-            src_plain = v->d_src_r; pair_slot = &v->d_src_r_zp;
-            srcD = v->D; srcH = v->W; pair_W = v->H; pair_P = v->Pr;
-            if (!v->tune.rswap_wfast) p.flags |= (1 << 24);          // h-fastest tile order on the transposed copy
-        }
-    }
-    if (plan.kind == 0) {
-        rc = plan_launch(v, m, flags, &p, &plan);
-        if (rc) return rc;
-    }
+    // single-axis rotations about axes 1 / 2 and in-plane maps near a quarter turn march on an exchanged resident copy
+    if ((rc = try_axis1_exchange(v, m, flags, n_out, &p, &plan, &ori))) return rc;
+    if (plan.kind == 0 && (rc = try_axis2_exchange(v, m, flags, n_out, &p, &plan, &ori))) return rc;
+    if (plan.kind == 0 && (rc = try_inplane_transposed(v, m, flags, n_out, &p, &plan, &ori))) return rc;
+    if (plan.kind == 0) plan_launch(v, m, flags, &p, &plan);
 
     float* d_out = out;
     const bool host_out = !(flags & VT_OUT_DEVICE);
     if (host_out) {
-        if (v->scratch_elems < n_out) {
-            if (v->d_scratch_out) { cached_free(v->dev, v->d_scratch_out, v->scratch_elems * sizeof(float)); v->d_scratch_out = nullptr; v->scratch_elems = 0; }
-            VT_HIP(cached_malloc(v->dev, reinterpret_cast<void**>(&v->d_scratch_out), n_out * sizeof(float)));
-            v->scratch_elems = n_out;
-        }
-        d_out = v->d_scratch_out;
+        if ((rc = host_output_buffer(v, n_out, &d_out))) return rc;
         if (flags & VT_KEEP_OUTSIDE)   // caller's stale values must survive: bring them in first
             VT_HIP(hipMemcpyAsync(d_out, out, n_out * sizeof(float), hipMemcpyHostToDevice, v->stream));
     }
     float* const d_final = d_out;
-    if (xswap) d_out = v->d_tmp_x;                // the kernels write the exchanged result [w][h][d]
-
-    if (plan.kind == 8) {
-        if (!*quad_slot) {
-            // build the plane-quad copy of the (prefiltered) resident source once; positions beyond the row's width stay zero
-            const size_t qbytes = (size_t)((srcD + 3) / 4) * srcH * p.sPq * sizeof(float);
-            VT_HIP(hipMalloc(reinterpret_cast<void**>(quad_slot), qbytes));
-            v->quad_bytes[quad_idx] = qbytes;
-            VT_HIP(hipMemsetAsync(*quad_slot, 0, qbytes, v->stream));
-            VT_HIP(launch_relayout_zquad(src_plain, *quad_slot, srcD, srcH, pair_W, pair_P, p.sPq, v->stream));
-        }
-        VT_HIP(launch_affine_quad(plan.cfg, v->interp, *quad_slot, d_out, p, plan.grid, plan.lds_bytes, v->stream));
-        v->last_kernel = 8;
-        v->last_tile[0] = plan.td; v->last_tile[1] = plan.th; v->last_tile[2] = plan.tw;
-        v->last_lds[0] = p.Lz; v->last_lds[1] = p.Ly; v->last_lds[2] = p.Lx;
-        v->last_lds_bytes = plan.lds_bytes; v->last_grid = plan.grid;
-    } else if (plan.kind == 5) {
-        if (!*pair_slot) {
-            // build the plane-pair copy of the (prefiltered) resident source once
-            v->P2 = p.sP2;
-            const size_t zbytes = (size_t)((srcD + 1) / 2) * srcH * v->P2 * sizeof(float);
-            VT_HIP(hipMalloc(reinterpret_cast<void**>(pair_slot), zbytes));
-            VT_HIP(hipMemsetAsync(*pair_slot, 0, zbytes, v->stream));
-            VT_HIP(launch_relayout_zpair(src_plain, *pair_slot, srcD, srcH, pair_W, pair_P, v->P2, v->stream));
-        }
-        VT_HIP(launch_affine_zpair(plan.cfg, v->interp, *pair_slot, d_out, p, plan.grid, plan.lds_bytes, v->stream));
-        v->last_kernel = 5;
-        v->last_tile[0] = plan.td; v->last_tile[1] = plan.th; v->last_tile[2] = plan.tw;
-        v->last_lds[0] = p.Lz; v->last_lds[1] = p.Ly; v->last_lds[2] = p.Lx;
-        v->last_lds_bytes = plan.lds_bytes; v->last_grid = plan.grid;
-    } else if (plan.kind == 6) {
-        VT_HIP(launch_affine_packed(plan.cfg, v->interp, v->d_src, d_out, v->d_zeros, p, plan.geo, plan.grid, plan.lds_bytes, v->stream));
-        v->last_kernel = 6;
-        v->last_tile[0] = plan.td; v->last_tile[1] = plan.th; v->last_tile[2] = plan.tw;
-        v->last_lds[0] = p.Lz; v->last_lds[1] = p.Ly; v->last_lds[2] = p.Lx;
-        v->last_lds_bytes = plan.lds_bytes; v->last_grid = plan.grid;
-    } else if (plan.kind == 4) {
-        VT_HIP(launch_affine_march(plan.cfg, v->interp, src_plain, d_out, p, plan.grid, plan.lds_bytes, v->stream));
-        v->last_kernel = 4;
-        v->last_tile[0] = plan.td; v->last_tile[1] = plan.th; v->last_tile[2] = plan.tw;
-        v->last_lds[0] = p.Lz; v->last_lds[1] = p.Ly; v->last_lds[2] = p.Lx;
-        v->last_lds_bytes = plan.lds_bytes; v->last_grid = plan.grid;
-    } else if (plan.kind >= 2) {
-        VT_HIP(launch_affine_tiled(plan.cfg, v->interp, plan.kind == 3, v->d_src, d_out, v->d_zeros, p, plan.grid, plan.lds_bytes, v->stream));
-        v->last_kernel = plan.kind;
-        v->last_tile[0] = plan.td; v->last_tile[1] = plan.th; v->last_tile[2] = plan.tw;
-        v->last_lds[0] = p.Lz; v->last_lds[1] = p.Ly; v->last_lds[2] = p.Lx;
-        v->last_lds_bytes = plan.lds_bytes; v->last_grid = plan.grid;
-    } else {
-        VT_HIP(launch_affine_direct(v->interp, v->d_src, d_out, p, v->stream));
-        v->last_kernel = 1;
-        v->last_tile[0] = v->last_tile[1] = v->last_tile[2] = 0;
-        v->last_lds[0] = v->last_lds[1] = v->last_lds[2] = 0;
-        v->last_lds_bytes = 0; v->last_grid = (int)((n_out + 255) / 256);
-    }
-
-    if (xswap) {
-        // [w][h][d] -> [d][h][w]
+    if (ori.xswap) d_out = v->d_tmp_x;            // the kernels write the exchanged result [w][h][d]
+    if ((rc = launch_planned(v, plan, p, ori, d_out, n_out))) return rc;
+    if (ori.xswap)                                // [w][h][d] -> [d][h][w]
         VT_HIP(launch_transpose02(v->d_tmp_x, d_final, v->oW, v->oH, v->oD, (int64_t)v->oH * v->oD, v->oD,
                                   (int64_t)v->oH * v->oW, v->oW, v->stream));
-        d_out = d_final;
-    }
     if (host_out) {
         PinnedScope pin(out, n_out * sizeof(float));
-        VT_HIP(hipMemcpyAsync(out, d_out, n_out * sizeof(float), hipMemcpyDeviceToHost, v->stream));
+        VT_HIP(hipMemcpyAsync(out, d_final, n_out * sizeof(float), hipMemcpyDeviceToHost, v->stream));
         VT_HIP(hipStreamSynchronize(v->stream));
     }
     return 0;
@@ -1442,41 +724,71 @@ int create_common(int dev, int D, int H, int W, int interp, const float* data, i
 // of 64 / 128 planes with 16 planes of warm-up, so each of its chunks is launched as soon as those planes are there (same
 // kernels, same chunk grid: the coefficients are the resident volume's, bit for bit).  Returns 1 when the call does not
 // qualify.
-int oneshot_pipelined(int dev, const float* h_volume, int D, int H, int W, int interp, const float* m4x4, float* h_out, int flags)
+// VT_PIPE_TRACE: host-side timeline and per-chunk event times of one pipelined one-shot call
+void pipeline_trace(double t_begin, double t_created, double t_pinned, double t_uploads, double t_slabs, double t_done, int nch,
+                    const std::vector<hipEvent_t>& ev_up, const std::vector<hipEvent_t>& ev_k, const std::vector<hipEvent_t>& ev_dn)
+{
+    std::fprintf(stderr, "[pipe] host: create %.2f  alloc+pin %.2f  enqueue uploads %.2f  enqueue slabs %.2f  drain %.2f  total %.2f ms\n",
+                 t_created - t_begin, t_pinned - t_created, t_uploads - t_pinned, t_slabs - t_uploads, t_done - t_slabs, t_done - t_begin);
+    for (int k = 0; k < nch; ++k) {
+        float a = 0, b = 0, c = 0;
+        hipEventElapsedTime(&a, ev_up[0], ev_up[(size_t)k]);
+        hipEventElapsedTime(&b, ev_up[0], ev_k[(size_t)k]);
+        hipEventElapsedTime(&c, ev_up[0], ev_dn[(size_t)k]);
+        std::fprintf(stderr, "[pipe] chunk %2d: upload done %+7.2f  kernel done %+7.2f  download done %+7.2f ms\n", k, a, b, c);
+    }
+}
+
+// may this call take the pipelined path?  (see oneshot_pipelined)
+bool pipeline_eligible(const float* h_volume, int D, int H, int W, int interp, const float* m4x4, const float* h_out, int flags)
 {
     const size_t n = (size_t)D * H * W;
     if ((flags & (VT_KEEP_OUTSIDE | VT_FORCE_DIRECT | VT_NO_ZSEP | VT_NO_MARCH)) || n * sizeof(float) < ((size_t)32 << 20) || D < 32)
-        return 1;
+        return false;
     {   // result written over the input (output=volume): slabs would be downloaded over planes still waiting to be uploaded
         const uintptr_t a0 = reinterpret_cast<uintptr_t>(h_volume), b0 = reinterpret_cast<uintptr_t>(h_out);
-        if (a0 < b0 + n * sizeof(float) && b0 < a0 + n * sizeof(float)) return 1;
+        if (a0 < b0 + n * sizeof(float) && b0 < a0 + n * sizeof(float)) return false;
     }
-    const bool filt = is_filtered(interp);
     // prefilter passes as run_prefilter orders them for such a volume: X in place, Y into the partner buffer, Z back
-    if (filt && (W > 2048 || prefilter_axis_in_place_ok(1, D, H, W) || prefilter_axis_in_place_ok(0, D, H, W))) return 1;
-    double m[16];
-    for (int i = 0; i < 16; ++i) m[i] = (double)m4x4[i];
-    if (!(m[0] == 1.0 && m[1] == 0.0 && m[2] == 0.0 && m[4] == 0.0 && m[8] == 0.0 && std::fabs(m[3]) < 1.0e9)) return 1;
+    if (is_filtered(interp) && (W > 2048 || prefilter_axis_in_place_ok(1, D, H, W) || prefilter_axis_in_place_ok(0, D, H, W))) return false;
+    double m[12];
+    for (int i = 0; i < 12; ++i) m[i] = (double)m4x4[i];
+    if (!(m[0] == 1.0 && m[1] == 0.0 && m[2] == 0.0 && m[4] == 0.0 && m[8] == 0.0 && std::fabs(m[3]) < 1.0e9)) return false;
     for (int i = 0; i < 12; ++i)
-        if (!std::isfinite(m[i])) return 1;
-    if (dev >= 64) return 1;
-    std::unique_lock<std::mutex> pipe_lock(g_cache[dev].pipe_mu, std::try_to_lock);
-    if (!pipe_lock.owns_lock()) return 1;          // another thread is in the pipeline on this device: plain sequence
-    // Three streams created back to back: the runtime deals hardware queues to streams round-robin (4 queues), and a
-    // download that shares its hardware queue with the kernels is executed in that queue, in order, by a shader copy at half
-    // the PCIe rate ([measured] kernel j only started when download j-1 had finished, 27 GB/s) -- so the pipeline's kernels
-    // run on a stream of their own, created with the two copy streams, not on whichever stream the handle got.
+        if (!std::isfinite(m[i])) return false;
+    return true;
+}
+
+// Three streams created back to back: the runtime deals hardware queues to streams round-robin (4 queues), and a
+// download that shares its hardware queue with the kernels is executed in that queue, in order, by a shader copy at half
+// the PCIe rate ([measured] kernel j only started when download j-1 had finished, 27 GB/s) -- so the pipeline's kernels
+// run on a stream of their own, created with the two copy streams, not on whichever stream the handle got.
+bool pipeline_streams(int dev)
+{
     hipStream_t& s_up = g_cache[dev].copy_up;
     hipStream_t& s_dn = g_cache[dev].copy_dn;
     hipStream_t& s_k = g_cache[dev].pipe_k;
-    if (!s_up || !s_dn || !s_k) {
-        if (hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&s_dn, hipStreamNonBlocking) != hipSuccess ||
-            hipStreamCreateWithFlags(&s_k, hipStreamNonBlocking) != hipSuccess) {
-            (void)hipGetLastError();
-            s_up = s_dn = s_k = nullptr;         // (a leaked stream on this error path is harmless)
-            return 1;
-        }
+    if (s_up && s_dn && s_k) return true;
+    if (hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&s_dn, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&s_k, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        s_up = s_dn = s_k = nullptr;         // (a leaked stream on this error path is harmless)
+        return false;
     }
+    return true;
+}
+
+int oneshot_pipelined(int dev, const float* h_volume, int D, int H, int W, int interp, const float* m4x4, float* h_out, int flags)
+{
+    const size_t n = (size_t)D * H * W;
+    if (dev >= 64 || !pipeline_eligible(h_volume, D, H, W, interp, m4x4, h_out, flags)) return 1;
+    const bool filt = is_filtered(interp);
+    double m[16];
+    for (int i = 0; i < 16; ++i) m[i] = (double)m4x4[i];
+    std::unique_lock<std::mutex> pipe_lock(g_cache[dev].pipe_mu, std::try_to_lock);
+    if (!pipe_lock.owns_lock()) return 1;          // another thread is in the pipeline on this device: plain sequence
+    if (!pipeline_streams(dev)) return 1;
+    hipStream_t s_up = g_cache[dev].copy_up, s_dn = g_cache[dev].copy_dn, s_k = g_cache[dev].pipe_k;
 
     static const bool trace = std::getenv("VT_PIPE_TRACE") != nullptr;
     auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1584,18 +896,8 @@ int oneshot_pipelined(int dev, const float* h_volume, int D, int H, int W, int i
     }
     const double t_slabs = now_ms();
     VT_HIPP(hipStreamSynchronize(s_dn));
-    if (trace) {
-        const double t_done = now_ms();
-        std::fprintf(stderr, "[pipe] host: create %.2f  alloc+pin %.2f  enqueue uploads %.2f  enqueue slabs %.2f  drain %.2f  total %.2f ms\n",
-                     t_created - t_begin, t_pinned - t_created, t_uploads - t_pinned, t_slabs - t_uploads, t_done - t_slabs, t_done - t_begin);
-        for (int k = 0; k < nch; ++k) {
-            float a = 0, b = 0, c = 0;
-            hipEventElapsedTime(&a, ev_up[0], ev_up[(size_t)k]);
-            hipEventElapsedTime(&b, ev_up[0], ev_k[(size_t)k]);
-            hipEventElapsedTime(&c, ev_up[0], ev_dn[(size_t)k]);
-            std::fprintf(stderr, "[pipe] chunk %2d: upload done %+7.2f  kernel done %+7.2f  download done %+7.2f ms\n", k, a, b, c);
-        }
-    }
+    if (trace)
+        pipeline_trace(t_begin, t_created, t_pinned, t_uploads, t_slabs, now_ms(), nch, ev_up, ev_k, ev_dn);
 #undef VT_HIPP
     return finish(0);
 }
@@ -1637,8 +939,7 @@ int do_affine_batch(vt_volume* v, int n, const double* m4x4s, float* out, int fl
     AffineParams p;
     std::memset(&p, 0, sizeof(p));
     TilePlan plan;
-    rc = plan_launch(v, ms.data(), (flags & VT_KEEP_OUTSIDE) | VT_FORCE_DIRECT, &p, &plan);   // dims, valid interval, flags
-    if (rc) return rc;
+    plan_launch(v, ms.data(), (flags & VT_KEEP_OUTSIDE) | VT_FORCE_DIRECT, &p, &plan);   // dims, valid interval, flags
     if (v->batch_m_cap < ms.size()) {
         if (v->d_batch_m) { VT_HIP(hipFree(v->d_batch_m)); v->d_batch_m = nullptr; v->batch_m_cap = 0; }
         VT_HIP(hipMalloc(reinterpret_cast<void**>(&v->d_batch_m), ms.size() * sizeof(double)));

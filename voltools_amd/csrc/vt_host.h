@@ -1,0 +1,111 @@
+// vt_host.h -- host-side declarations shared by the C ABI (vt_api.hip) and the launch planner (vt_plan.hip).
+#pragma once
+#include "vt_internal.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
+// Experiment overrides, read from the environment once per handle (vt_volume_create) -- never on the per-call path.
+// None is needed in production; tools/*.sh and the staging-mode parity test use them to reach planner alternatives.
+struct Tuning {
+    int tile = -1;                 // VT_TILE: force tile configuration (index into the kernel family's table)
+    int la = 0;                    // VT_LA: planes / pairs staged ahead by the marching kernels
+    int march_box = -1;            // VT_MARCH_BOX: 1 = bounding-box staging, 0 = packed row spans, -1 = planner's choice
+    int lxpad = -1;                // VT_LXPAD: LDS row padding of the pair kernel's boxes
+    int dch = 0;                   // VT_DCH: output planes per marching chunk
+    int blk_h = -1, blk_w = -1;    // VT_BLK_H / VT_BLK_W: blocked tile order of the marching kernels (tiles per block; 0 = plain order)
+    bool plain_tile_order = false; // VT_TILE_ORDER=0: packed kernel walks tiles in plain instead of blocked order
+    bool rswap_wfast = false;      // VT_RSWAP_WFAST: keep the w-fastest tile order on the in-plane transposed copy
+    bool exp_nostore = false;      // VT_EXP_NOSTORE / VT_EXP_NOLOAD / VT_EXP_NOLDS: ablation builds (-DVT_EXPERIMENTS) only
+    bool exp_noload = false;
+    bool exp_nolds = false;
+    bool exp_noloop = false;
+    int quad_nt = -1;              // VT_QUAD_NT: 1 / 0 = nontemporal / plain output stores of the plane-quad kernel, -1 = planner's choice
+    void read()
+    {
+        auto num = [](const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; };
+        tile = num("VT_TILE", -1);
+        la = num("VT_LA", 0);
+        march_box = num("VT_MARCH_BOX", -1);
+        if (march_box > 1) march_box = 1;
+        lxpad = num("VT_LXPAD", -1);
+        dch = std::max(0, num("VT_DCH", 0));
+        blk_h = num("VT_BLK_H", -1);
+        blk_w = num("VT_BLK_W", -1);
+        plain_tile_order = num("VT_TILE_ORDER", 1) == 0;
+        rswap_wfast = std::getenv("VT_RSWAP_WFAST") != nullptr;
+        exp_nostore = std::getenv("VT_EXP_NOSTORE") != nullptr;
+        exp_noload = std::getenv("VT_EXP_NOLOAD") != nullptr;
+        exp_nolds = std::getenv("VT_EXP_NOLDS") != nullptr;
+        exp_noloop = std::getenv("VT_EXP_NOLOOP") != nullptr;
+        quad_nt = num("VT_QUAD_NT", -1);
+    }
+};
+
+
+struct vt_volume {
+    int dev = 0;
+    int interp = 0;
+    int D = 0, H = 0, W = 0;           // resident source dims
+    int oD = 0, oH = 0, oW = 0;        // output dims
+    int64_t plane0 = 0;                // global index of resident plane 0
+    int64_t gD = 0;                    // global depth
+    int64_t out_plane0 = 0;            // global index of output plane 0
+    int P = 0;                         // row pitch of d_src in floats: W rounded up to 4, pad columns hold 0
+    float* d_src = nullptr;
+    size_t src_bytes = 0;              // size of the d_src allocation (small ones are recycled per device)
+    float* d_zeros = nullptr;          // 16 bytes of zeros: the border fetch target of the tiled kernel
+    float* d_src_zp = nullptr;         // second resident copy, planes interleaved in pairs (cubic marching kernel); lazy
+    float* d_src_t = nullptr;          // resident copy with axes 0 and 1 exchanged (rotations about axis 1 march along it); lazy
+    float* d_src_t_zp = nullptr;       // ... and its plane-pair form; lazy
+    float* d_src_r = nullptr;          // resident copy transposed in-plane ([z][x][y], pitch Pr; quarter-turn class of in-plane maps); lazy
+    float* d_src_r_zp = nullptr;       // ... and its plane-pair form; lazy
+    int Pr = 0;
+    float* d_src_x = nullptr;          // resident copy with axes 0 and 2 exchanged ([x][y][z], pitch Px; rotations about axis 2); lazy
+    float* d_src_x_zp = nullptr;       // ... and its plane-pair form; lazy
+    int Px = 0;
+    float* d_tmp_x = nullptr;          // exchanged result of an axis-2 launch, before it is turned back
+    size_t tmp_x_elems = 0;
+    float* d_src_q = nullptr;          // plane-quad copies ([z/4][y][x][4]; vt_kernels_quad.hip) of the four orientations; lazy
+    float* d_src_t_q = nullptr;
+    float* d_src_r_q = nullptr;
+    float* d_src_x_q = nullptr;
+    size_t quad_bytes[4] = {0, 0, 0, 0};   // allocation sizes of the four quad copies (vt_volume_info)
+    int P2 = 0;                        // floats per pair-row of d_src_zp
+    float* d_scratch_out = nullptr;    // staging for host outputs
+    double* d_batch_m = nullptr;       // batch launches: n x 12 folded matrices
+    std::vector<double> h_batch_m;     // ... and their host staging (must outlive the asynchronous upload)
+    size_t batch_m_cap = 0;
+    float* d_proj_tmp = nullptr;       // projection of general matrices: the transformed volume before the sum
+    size_t proj_tmp_elems = 0;
+    vt_volume* proj = nullptr;         // projection helper: 3 x H x W volume [S, S, S] sharing this handle's stream
+    bool owns_stream = true;
+    size_t scratch_elems = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float prefilter_ms = 0.f;
+    int lds_limit = 160 * 1024;
+    int cu_count = 256;
+    // last launch, for vt_volume_info
+    int last_kernel = 0, last_tile[3] = {0, 0, 0}, last_lds[3] = {0, 0, 0}, last_lds_bytes = 0, last_grid = 0;
+    Tuning tune;                       // experiment overrides (environment, read at create)
+};
+
+namespace vt {
+
+inline bool is_cubic(int interp) { return interp != VT_LINEAR; }
+inline bool is_filtered(int interp) { return interp == VT_FILT_BSPLINE || interp == VT_FILT_BSPLINE_SIMPLE; }
+
+// Row pitch of a resident plain-layout copy, in floats: the row's samples, at least one all-zero 16-byte vector after them
+// (the border fetch target), rounded up so that EVERY ROW STARTS ON A 128-BYTE CACHE LINE.  With the round-1 pitch
+// (roundup4(W) + 4: 2064 bytes at W = 512) every row segment a strided prefilter pass stores straddled cache lines:
+// partial-line writes, [measured] 2.0 instead of 5.2 TB/s for tile-shaped stores (tools/probes/pattern_probe.hip, pitch 520)
+// and 0.32 ms per strided pass at 512^3 whatever the load width.  Costs 6 % more resident bytes at 512, 3 % at 1024.
+inline int resident_pitch(int W) { return (W + 4 + 31) & ~31; }
+
+// The launch planner (vt_plan.hip): kernel family, tile shape, LDS budget and grid for one matrix on one handle.  Fills every
+// field of `p` the chosen kernel reads; plan->kind = 1 (direct gather) when nothing tiled fits.  Host side, ~10 us.
+void plan_launch(const vt_volume* v, const double m[12], int flags, AffineParams* p, TilePlan* plan);
+
+}  // namespace vt

@@ -1,0 +1,744 @@
+// vt_plan.hip -- the launch planner: which kernel family serves a matrix on a handle, with which tile, LDS budget and grid.
+//
+// One `plan_*` function per kernel family, tried in order of preference by `plan_launch` (kFamilies); each checks its own
+// eligibility (matrix class, diagnostic flags, address ranges, LDS fit), fills the AffineParams fields its kernel reads and
+// returns true, or leaves the plan untouched and returns false.  Host side, a few hundred flops (~10 us); the environment knobs
+// of the experiments are gathered in vt_volume::tune (vt_host.h).
+//
+//   family   kind  kernel (file)                                   serves
+//   quad       8   affine_march4       (vt_kernels_quad.hip)       axis-0-separable matrices, every interpolation
+//   zpair      5   affine_march_zpair  (vt_kernels_march.hip)      axis-0-separable, cubic   (VT_NO_QUAD)
+//   march      4   affine_march_zsep   (vt_kernels_march.hip)      axis-0-separable          (VT_NO_QUAD / VT_NO_ZPAIR)
+//   box      2, 3  affine_tiled[_zsep] (vt_kernels_affine.hip)     any matrix whose tile footprint's bounding box fits LDS
+//   packed     6   affine_tiled_packed (vt_kernels_packed.hip)     invertible general matrices, trilinear (or forced)
+//   direct     1   affine_direct       (vt_kernels_affine.hip)     everything else (tiny volumes, huge footprints)
+#include "vt_host.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace vt {
+namespace {
+
+struct PlanCtx {
+    const vt_volume* v;
+    const double* m;           // folded 3 x 4 matrix (resident coordinates)
+    int flags;
+    AffineParams* p;
+    TilePlan* plan;
+    bool cubic;
+    bool zsep;                 // [1 0 0 tz; 0 a b ty; 0 c d tx]
+    int halo2;                 // extra taps of the cubic stencil on each side (0 / 2 in total)
+};
+
+// Chunk count of a marching launch.  Its workgroups all do the same work, so the chip runs them in rounds of `resident`
+// workgroups and a launch of 5.33 rounds takes almost as long as one of 6 ([measured] 512^3 cubic at 0 / 30 degrees:
+// 8 chunks = 5.33 rounds 0.274 / 0.304 ms; 6 chunks = 4.0 rounds 0.261 / 0.296; 3 chunks = 2.0 rounds 0.249 / 0.297;
+// 4 chunks = 2.67 rounds 0.260 / 0.314; tools/dch_rounds.sh).  Among chunk counts from n0/4 to 2*n0 take the one with the
+// least rounds x planes marched per chunk, a partial round charged at its fraction + 0.3; launches of many rounds (>= 16)
+// or of less than one keep n0, and so do planes with more tiles than the chip keeps resident (there deeper chunks
+// separate in-plane neighbours in time and their shared rows miss L2: 640^3 cubic 0.544 vs 0.498 ms).  Used by the pair
+// kernel only ([measured] 256^3 -9..-12 %, 384^3 -6..-10 %, 512^3 -2..-8 %).  `extra` = source planes a chunk stages beyond
+// its output planes.
+int64_t round_aware_chunks(int64_t oD, int g, int64_t inplane, int64_t resident, int64_t n0, int extra, int min_dch, int64_t n_floor)
+{
+    if (resident <= 0 || inplane > resident || inplane * n0 >= 16 * resident) return n0;
+    auto cost = [&](int64_t n) {
+        int64_t dch = (oD + n - 1) / n;
+        dch = (dch + g - 1) / g * g;
+        const int64_t n_act = (oD + dch - 1) / dch;
+        const double R = (double)(inplane * n_act) / (double)resident;
+        if (R < 1.0) return 1e300;
+        const double fl = std::floor(R), fr = R - fl;
+        return (fl + (fr > 1e-9 ? std::min(1.0, fr + 0.3) : 0.0)) * (double)(dch + extra);
+    };
+    int64_t best = n0;
+    double best_c = cost(n0);
+    if (best_c >= 1e300) return n0;
+    best_c *= 0.97;                                   // switch only for a predicted gain of 3 % or more
+    const int64_t lo = std::max<int64_t>(std::max<int64_t>(1, n_floor), n0 / 4);
+    const int64_t hi = std::min<int64_t>(2 * n0, std::max<int64_t>(1, oD / std::max(1, min_dch)));
+    for (int64_t n = hi; n >= lo; --n) {
+        const double c = cost(n);
+        if (c < best_c) { best_c = c; best = n; }
+    }
+    return best;
+}
+
+// Expected LDS cycles of one half-wave `ds_read2_b32` of the gather (relative to conflict-free = 1.0) when lanes
+// step by (a, b) in (row, column) through an LDS image with row stride Lx: for each of the two dwords, the number
+// of distinct addresses on the busiest of the 32 banks (identical addresses broadcast).  Averaged over a few
+// sub-voxel offsets.  Used to choose the row stride of the marching cubic kernels, which are LDS-bound.
+double gather_conflict_factor(double a, double b, int Lx, int ndw = 2)
+{
+    double total = 0;
+    int samples = 0;
+    for (int oy = 0; oy < 2; ++oy)
+        for (int ox = 0; ox < 2; ++ox) {
+            const double y0 = 8.0 + 0.37 * oy + 40.0 * std::fabs(std::min(a, 0.0)), x0 = 8.0 + 0.41 * ox + 40.0 * std::fabs(std::min(b, 0.0));
+            for (int dw = 0; dw < ndw; ++dw) {
+                int count[32];
+                int addrs[32][32];
+                for (int i = 0; i < 32; ++i) count[i] = 0;
+                for (int l = 0; l < 32; ++l) {
+                    const int addr = (int)std::floor(y0 + a * l) * Lx + (int)std::floor(x0 + b * l) + dw;
+                    const int bank = addr & 31;
+                    bool seen = false;
+                    for (int k = 0; k < count[bank]; ++k) seen = seen || (addrs[bank][k] == addr);
+                    if (!seen) addrs[bank][count[bank]++] = addr;
+                }
+                int worst = 1;
+                for (int i = 0; i < 32; ++i) worst = std::max(worst, count[i]);
+                total += worst;
+                ++samples;
+            }
+        }
+    return total / samples;
+}
+
+
+// Upper estimate of the packed footprint of a TH x TW in-plane tile (16-byte vectors per source plane) under rows 1, 2 of
+// the matrix, as the marching kernel packs it: per source row the tapped span, aligned to 16 bytes.  The tile's sub-voxel
+// position varies from tile to tile, so a 4 x 4 grid of offsets is sampled and a margin added; a tile that still exceeds
+// the slot falls back to a direct gather inside the kernel, so the estimate affects speed only.
+int estimate_packed_vectors(const double m[12], int th, int tw, int halo, int rows_cap, int* rows_out)
+{
+    const double a1 = m[5], b1 = m[6], a2 = m[9], b2 = m[10];       // d(sy)/dj, d(sy)/dk, d(sx)/dj, d(sx)/dk
+    const double ia1 = march_recip(a1), ib1 = march_recip(b1);
+    double neg1 = 0, neg2 = 0;
+    for (double e : {a1 * (th - 1), b1 * (tw - 1)}) if (e < 0) neg1 += e;
+    for (double e : {a2 * (th - 1), b2 * (tw - 1)}) if (e < 0) neg2 += e;
+    int worst = 0, worst_rows = 0;
+    for (int oy = 0; oy < 3; ++oy)
+        for (int ox = 0; ox < 3; ++ox) {
+            // box-relative base exactly as the kernel forms it: lo = base + neg, o = floor(lo) - halo, b = base - o
+            const double fy0 = 0.33 * oy + 0.013, fx0 = 0.33 * ox + 0.017;
+            const double by = fy0 - neg1 + halo, bx = fx0 - neg2 + halo;   // (+ up to 3 for the 16-byte alignment of o2)
+            int total = 0, rows = 0;
+            for (int Y = 0; Y < rows_cap; ++Y) {       // rows_cap: the bounding box's rows (+1)
+                int mn, mx;
+                if (!march_row_span(a1, b1, a2, b2, ia1, ib1, by, bx, Y, th, tw, halo, &mn, &mx)) continue;
+                total += ((mx - mn) >> 2) + 2;                   // +1 vector: unknown 16-byte phase of the span start
+                rows = Y + 1;
+            }
+            worst = std::max(worst, total);
+            worst_rows = std::max(worst_rows, rows);
+        }
+    *rows_out = worst_rows + 1;
+    return worst + worst / 64 + 2;
+}
+
+
+// Upper estimate of the packed footprint of a TH x TW in-plane tile in POSITIONS (plane-quad layout: one 16-byte vector per
+// position, no alignment), as affine_march4 packs it.  A 3 x 3 grid of sub-voxel offsets is sampled; a row's span changes by
+// at most one position with the offset, hence the margin of one position per row.  A tile that still exceeds the slot
+// takes the kernel's direct-gather path (slow, never wrong).
+int estimate_span_positions(const double m[12], int th, int tw, int halo, int rows_cap, int* rows_out)
+{
+    const double a1 = m[5], b1 = m[6], a2 = m[9], b2 = m[10];
+    const double ia1 = march_recip(a1), ib1 = march_recip(b1);
+    double neg1 = 0, neg2 = 0;
+    for (double e : {a1 * (th - 1), b1 * (tw - 1)}) if (e < 0) neg1 += e;
+    for (double e : {a2 * (th - 1), b2 * (tw - 1)}) if (e < 0) neg2 += e;
+    int worst = 0, worst_rows = 0;
+    for (int oy = 0; oy < 3; ++oy)
+        for (int ox = 0; ox < 3; ++ox) {
+            const double by = 0.33 * oy + 0.013 - neg1 + halo, bx = 0.33 * ox + 0.017 - neg2 + halo;
+            int total = 0, rows = 0;
+            for (int Y = 0; Y < rows_cap; ++Y) {
+                int mn, mx;
+                if (!march_row_span(a1, b1, a2, b2, ia1, ib1, by, bx, Y, th, tw, halo, &mn, &mx)) continue;
+                total += mx - mn + 1;
+                rows = Y + 1;
+            }
+            worst = std::max(worst, total);
+            worst_rows = std::max(worst_rows, rows);
+        }
+    *rows_out = worst_rows + 1;
+    return worst + worst_rows + 8;
+}
+
+
+// Source extent of an in-plane TH x TW tile under rows 1, 2 of the matrix (+ taps), in rows / columns; false when absurd.
+bool inplane_box(const double m[12], int th, int tw, int halo2, int L[3])
+{
+    const int T[3] = {1, th, tw};
+    L[0] = 0;
+    for (int r = 1; r < 3; ++r) {
+        double ext = 0;
+        for (int k = 1; k < 3; ++k) ext += std::fabs(m[4 * r + k]) * (T[k] - 1);
+        if (!(ext < 4096.0)) return false;
+        L[r] = (int)std::floor(ext) + 3 + halo2;
+    }
+    return true;
+}
+
+// neg / pos: lowest / highest source coordinate of a tile relative to its base, over tile axes k0 .. 2
+void set_tile_reach(AffineParams* p, const double m[12], const int T[3], int k0)
+{
+    for (int r = 0; r < 3; ++r) {
+        double neg = 0, pos = 0;
+        for (int k = k0; k < 3; ++k) {
+            const double e = m[4 * r + k] * (T[k] - 1);
+            if (e < 0) neg += e; else pos += e;
+        }
+        p->neg[r] = neg; p->pos[r] = pos;
+    }
+}
+
+void set_axis0_split(AffineParams* p, const double m[12])
+{
+    const double fl = std::floor(m[3]);
+    p->zoff = (int32_t)fl;
+    p->fz = (float)(m[3] - fl);
+}
+
+int experiment_flags(const vt_volume* v)
+{
+    return (v->tune.exp_nostore ? (1 << 21) : 0) | (v->tune.exp_noload ? (1 << 22) : 0) | (v->tune.exp_nolds ? (1 << 26) : 0) |
+           (v->tune.exp_noloop ? (1 << 27) : 0);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// quad: marching kernel on the plane-quad layout (kind 8)
+// ---------------------------------------------------------------------------------------------------
+bool quad_pick_tile(PlanCtx& c, int64_t max_stride)
+{
+    const vt_volume* v = c.v;
+    AffineParams* p = c.p;
+    const int halo = c.cubic ? 1 : 0;
+    for (int cfg = 0; cfg < quad_config_count(); ++cfg) {
+        if (v->tune.tile >= 0 && cfg != v->tune.tile) continue;
+        int th, tw, nt;
+        quad_config(cfg, &th, &tw, &nt);
+        if ((int64_t)th * max_stride * 4 >= 0x7fffffffLL) continue;
+        int L[3];
+        if (!inplane_box(c.m, th, tw, c.halo2, L) || L[1] > march_rows_max()) continue;
+        int rows = 0;
+        const int npos = estimate_span_positions(c.m, th, tw, halo, L[1] + 1, &rows);
+        if (rows > march_rows_max()) continue;
+        const int nvec64 = (npos + 63) & ~63;
+        if (nvec64 > nt * march_max_it()) continue;
+        const int slot_bytes = nvec64 * 16;                   // two ring slots; slot 1 sits at offset slot_bytes (toggled with XOR)
+        const int64_t bytes = std::max<int64_t>(2LL * slot_bytes, march_table_bytes());
+        if (bytes > v->lds_limit) continue;
+        c.plan->kind = 8; c.plan->cfg = cfg; c.plan->td = 4; c.plan->th = th; c.plan->tw = tw;
+        c.plan->lds_bytes = (int)bytes;
+        p->Lz = 2; p->Ly = std::min(L[1], march_rows_max()); p->Lx = npos; p->Lx_used = npos;
+        p->slot_floats = slot_bytes / 4;
+        return true;                              // configurations are listed in order of preference: first fit wins
+    }
+    return false;
+}
+
+bool plan_quad(PlanCtx& c)
+{
+    const vt_volume* v = c.v;
+    AffineParams* p = c.p;
+    TilePlan* plan = c.plan;
+    if (!c.zsep || (c.flags & (VT_NO_MARCH | VT_NO_QUAD | VT_NO_ZPAIR))) return false;
+    const int halo = c.cubic ? 1 : 0;
+    const int Wq = (v->W + 1 + 7) & ~7;                    // positions per quad-row: >= one zero position, rows of whole 128-byte lines
+    const int64_t quad_bytes = (int64_t)v->H * Wq * 16;
+    if (quad_bytes >= 0x7fffffffLL) return false;
+    // output addressing of the kernel: 31-bit byte offsets inside a tile (rows) and inside a chunk (planes), for either
+    // orientation of the output strides (axis-exchanged launches swap them afterwards)
+    const int64_t max_stride = (int64_t)std::max(v->oD, v->oH) * v->oW;
+    const TilePlan saved = *plan;
+    if (!quad_pick_tile(c, max_stride)) return false;
+    const int T[3] = {1, plan->th, plan->tw};
+    set_tile_reach(p, c.m, T, 1);
+    set_axis0_split(p, c.m);
+    p->nTh = (v->oH + plan->th - 1) / plan->th;
+    p->nTw = (v->oW + plan->tw - 1) / plan->tw;
+    p->sPq = 4 * Wq;
+    p->zero_off_q = v->W * 16;
+    p->flags = (c.flags & VT_KEEP_OUTSIDE) | experiment_flags(v);
+    if (v->tune.quad_nt < 0 ? true : v->tune.quad_nt != 0) p->flags |= (1 << 28);     // streaming output stores ([measured] +2..5 % in-process)
+    const int64_t inplane = (int64_t)p->nTh * p->nTw;
+    // chunk depth: every chunk pays one quad step beyond its own planes (history of the first outputs), so chunks are deeper than
+    // the plain kernels' -- but short-lived workgroups keep the write stream compact (tools/probes/pattern_probe.hip).
+    // [measured, tools/march_ab.py] trilinear: 24 planes where a whole layer of tiles is resident at once (512^3: 0.204 vs 0.213 ms
+    // at 76), 64 on larger planes (1024^3: 1.70 at 64, 1.77 at 32, 1.82 at 128); cubic, chunk starts aligned to quads (dshift):
+    // 512^3 0.227 ms at 64 planes, 0.233 at 128, 0.236 at 256
+    int target_dch = (!c.cubic && (int64_t)v->H * v->W <= 512 * 512) ? 24 : 64;
+    if (v->tune.dch > 0) target_dch = std::max(4, v->tune.dch);
+    int64_t nchunks = std::max<int64_t>(1, (v->oD + target_dch - 1) / target_dch);
+    // small volumes: shorter chunks until the launch has ~4 workgroups per CU, not below 8 planes per chunk
+    if (v->tune.dch <= 0)
+        nchunks = std::max(nchunks, std::min<int64_t>((4 * (int64_t)v->cu_count + inplane - 1) / inplane, (v->oD + 7) / 8));
+    // scalar byte offsets: source quads of a chunk from its first quad, output planes from its first plane (31 bits each)
+    const int64_t n_addr = std::max(((int64_t)(v->oD / 4 + 4) * quad_bytes) / 0x60000000LL + 1, ((int64_t)v->oD * max_stride * 4) / 0x60000000LL + 1);
+    nchunks = std::max<int64_t>(nchunks, n_addr);
+    plan->blocks_per_cu = quad_blocks_per_cu(plan->cfg, v->interp, plan->lds_bytes);
+    int dch = (int)((v->oD + nchunks - 1) / nchunks);
+    dch = (dch + 3) & ~3;
+    // chunk boundaries at c*dch + dshift: the first tap plane of every chunk but the first, d_begin + zoff - halo, is then the
+    // first plane of a quad -- a cubic chunk marches dch/4 + 1 quads instead of dch/4 + 2 (64 planes: 17 steps instead of 18)
+    const int dshift = (int)((((int64_t)halo - (int64_t)p->zoff) % 4 + 4) % 4);
+    nchunks = (v->oD > dshift) ? (v->oD - dshift + dch - 1) / dch : 1;
+    const int64_t grid = inplane * nchunks;
+    if ((int64_t)(dch + dshift) * max_stride * 4 >= 0x7fffffffLL || grid > 0x7fffffffLL) { *plan = saved; return false; }
+    p->dch = dch;
+    p->dshift = dshift;
+    p->nTd = (int)nchunks;
+    if (v->tune.blk_h > 0 && v->tune.blk_w > 0) { p->blk_h = v->tune.blk_h; p->blk_w = v->tune.blk_w; }
+    plan->grid = (int)grid;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// zpair: cubic marching kernel on the plane-pair layout (kind 5)
+// ---------------------------------------------------------------------------------------------------
+bool zpair_pick_tile(PlanCtx& c)
+{
+    const vt_volume* v = c.v;
+    AffineParams* p = c.p;
+    const double* m = c.m;
+    for (int cfg = 0; cfg < zpair_config_count(); ++cfg) {
+        if (v->tune.tile >= 0 && cfg != v->tune.tile) continue;
+        int th, tw, la, nt;
+        zpair_config(cfg, &th, &tw, &la, &nt);
+        if (v->tune.la > 0) la = std::min(3, v->tune.la);
+        const int vec_max = nt * march_max_it();
+        int L[3];
+        if (!inplane_box(m, th, tw, c.halo2, L)) continue;
+        L[2] = (L[2] + 1 + 1) & ~1;                      // origin aligned down by up to 1 position, even width
+        // boxes (stride padding fetched from the zero vector) vs packed spans [measured]: 512^3 sweep mean 0.292 vs
+        // 0.312 ms, 1024^3 2.25-2.33 vs 2.28-2.38 ms -> boxes; VT_MARCH_BOX=0 selects packed spans
+        bool zp_box = true;
+        if (v->tune.march_box >= 0) zp_box = v->tune.march_box != 0;
+        const int lx_used = L[2];                         // columns that hold data; the rest is stride padding
+        int best_lx = L[2];
+        double best_f = 1e300;
+        for (int pad = 0; pad <= 30; pad += 2) {         // bank-pair index = (y*Lx + x) mod 32 for ds_read_b64
+            // [measured at 36 and 144 degrees] every 2 positions of padding cost ~3 % (LDS footprint), a
+            // pathological stride costs 30-50 %: the model flags the pathological ones reliably
+            if (pad > 0 && L[1] * ((L[2] + pad) / 2) > vec_max) break;     // the padded box must still be stageable
+            const double f = gather_conflict_factor(m[6], m[10], L[2] + pad, 1) * (1.0 + 0.015 * pad);
+            if (f < best_f - 1e-9) { best_f = f; best_lx = L[2] + pad; }
+        }
+        if (v->tune.lxpad >= 0) best_lx = L[2] + v->tune.lxpad;
+        L[2] = best_lx;
+        int slot_floats = L[1] * L[2] * 2;
+        if (!zp_box) {
+            int rows = 0;
+            // packed spans: vectors of 2 positions; the estimate counts 4-position vectors, so double it (loose)
+            const int vecs = 2 * estimate_packed_vectors(m, th, tw, 1, L[1] + 1, &rows);
+            if (rows > march_rows_max() || L[1] > march_rows_max()) continue;
+            slot_floats = vecs * 4;
+            if (vecs > vec_max) continue;
+        } else if (L[1] * (L[2] / 2) > vec_max) continue;
+        // planes with far more tiles than the chip keeps resident: one more pair in flight where three slots still
+        // leave three workgroups per CU ([measured] 1024^3: 2.020 -> 1.972 ms at 0 degrees, 2.221 -> 2.202 at 30;
+        // 512^3, whole layers resident: 0.258 -> 0.263, so not there)
+        if (v->tune.la <= 0 && la == 1 && 9LL * slot_floats * 4 <= 160 * 1024 &&
+            (int64_t)((v->oH + th - 1) / th) * ((v->oW + tw - 1) / tw) > 7LL * v->cu_count)    // 640^3, 768^3: -2..-4 % with it
+            la = 2;
+        const int64_t bytes = std::max<int64_t>((int64_t)(la + 1) * slot_floats * 4, zp_box ? 0 : march_table_bytes());
+        if (bytes > v->lds_limit) continue;
+        c.plan->kind = 5; c.plan->cfg = cfg; c.plan->td = 2; c.plan->th = th; c.plan->tw = tw;
+        c.plan->lds_bytes = (int)bytes;
+        p->Lz = la + 1; p->Ly = L[1]; p->Lx = L[2]; p->Lx_used = lx_used;
+        p->slot_floats = slot_floats;
+        p->flags = (c.flags & VT_KEEP_OUTSIDE) | (zp_box ? (1 << 20) : 0) | experiment_flags(v);
+        return true;
+    }
+    return false;
+}
+
+bool plan_zpair(PlanCtx& c)
+{
+    const vt_volume* v = c.v;
+    AffineParams* p = c.p;
+    TilePlan* plan = c.plan;
+    if (!c.zsep || !c.cubic || (c.flags & (VT_NO_MARCH | VT_NO_ZPAIR))) return false;
+    if ((int64_t)v->H * v->P * 4 >= 0x7fffffffLL || (int64_t)v->H * (2 * (((v->W + 3) & ~3) + 4)) * 4 >= 0x7fffffffLL) return false;
+    const TilePlan saved = *plan;
+    if (!zpair_pick_tile(c)) return false;
+    const int T[3] = {1, plan->th, plan->tw};
+    set_tile_reach(p, c.m, T, 1);
+    set_axis0_split(p, c.m);
+    p->nTh = (v->oH + plan->th - 1) / plan->th;
+    p->nTw = (v->oW + plan->tw - 1) / plan->tw;
+    p->sP2 = 2 * (((v->W + 3) & ~3) + 4);
+    p->zero_off2 = 2 * ((v->W + 3) & ~3) * 4;
+    const int64_t inplane = (int64_t)p->nTh * p->nTw;
+    int target_dch = ((int64_t)v->H * v->W <= 512 * 512) ? 64 : 32;
+    if (v->tune.dch > 0) target_dch = std::max(2, v->tune.dch);
+    int64_t nchunks = std::max<int64_t>(1, (v->oD + target_dch - 1) / target_dch);
+    // small volumes: shorter chunks until the launch has ~4 workgroups per CU (a 128^3 volume has only 32
+    // in-plane tiles: 64-plane chunks would leave 3/4 of the chip idle), but not below 8 planes per chunk
+    if (v->tune.dch <= 0)
+        nchunks = std::max(nchunks, std::min<int64_t>((4 * (int64_t)v->cu_count + inplane - 1) / inplane, (v->oD + 7) / 8));
+    const int64_t pair_bytes = (int64_t)v->H * p->sP2 * 4;
+    const int64_t n_addr = ((int64_t)(v->oD / 2 + 4) * pair_bytes) / 0x60000000LL + 1;   // 31-bit scalar offsets
+    nchunks = std::max<int64_t>(nchunks, n_addr);
+    if (v->tune.dch <= 0)
+        nchunks = round_aware_chunks(v->oD, 2, inplane, (int64_t)v->cu_count * march_blocks_per_cu(true, plan->cfg, v->interp, plan->lds_bytes),
+                                     nchunks, 4, 8, n_addr);
+    int dch = (int)((v->oD + nchunks - 1) / nchunks);
+    dch = (dch + 1) & ~1;
+    nchunks = (v->oD + dch - 1) / dch;
+    p->dch = dch;
+    p->nTd = (int)nchunks;
+    if (v->tune.blk_h > 0 && v->tune.blk_w > 0) { p->blk_h = v->tune.blk_h; p->blk_w = v->tune.blk_w; }
+    const int64_t grid = inplane * nchunks;
+    if (grid > 0x7fffffffLL) { *plan = saved; return false; }
+    plan->grid = (int)grid;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// march: marching kernel on the plain layout (kind 4)
+// ---------------------------------------------------------------------------------------------------
+bool march_pick_tile(PlanCtx& c)
+{
+    const vt_volume* v = c.v;
+    AffineParams* p = c.p;
+    const double* m = c.m;
+    // Footprint staging: the linear kernels stage the packed row spans of the rotated tile (least traffic, least
+    // LDS).  The cubic kernels are LDS-read-bound and sensitive to bank conflicts, which the irregular row starts
+    // of the packed image make worse (measured 0.48 vs 0.39 ms at 45 degrees), so they stage the bounding box with
+    // a conflict-aware row stride.  VT_MARCH_BOX=0/1 overrides.
+    bool march_box = c.cubic;
+    if (v->tune.march_box >= 0) march_box = v->tune.march_box != 0;
+    for (int cfg = 0; cfg < march_config_count(); ++cfg) {
+        if (v->tune.tile >= 0 && cfg != v->tune.tile) continue;
+        int th, tw, g, la, nt;
+        march_config(cfg, &th, &tw, &g, &la, &nt);
+        if (v->tune.la > 0) la = v->tune.la;
+        const int vec_max = nt * march_max_it();
+        int L[3];
+        if (!inplane_box(m, th, tw, c.halo2, L) || L[1] > march_rows_max()) continue;
+        int rows = 0;
+        const int vecs = estimate_packed_vectors(m, th, tw, c.cubic ? 1 : 0, L[1] + 1, &rows);
+        if (vecs > vec_max || rows > march_rows_max()) continue;
+        int slot_floats = vecs * 4;
+        int lx_used4 = 0;
+        if (march_box) {
+            // full bounding box with the row stride (in 16-byte steps) that predicts the fewest bank conflicts for
+            // this matrix' lane step (m[1][2], m[2][2])
+            L[2] = (L[2] + 3 + 3) & ~3;
+            lx_used4 = L[2];
+            int best_lx = L[2];
+            double best_f = 1e300;
+            for (int pad = 0; pad <= 28; pad += 4) {
+                if (pad > 0 && L[1] * (L[2] + pad) / 4 > vec_max) break;
+                const double f = gather_conflict_factor(m[6], m[10], L[2] + pad) * (1.0 + 0.015 * pad);
+                if (f < best_f - 1e-9) { best_f = f; best_lx = L[2] + pad; }
+            }
+            L[2] = best_lx;
+            slot_floats = L[1] * L[2];
+            if (L[1] * L[2] / 4 > vec_max) continue;
+        }
+        const int ring = (la + 1) * g + c.halo2 + 1;
+        const int64_t bytes = std::max<int64_t>((int64_t)ring * slot_floats * 4, march_box ? 1024 : march_table_bytes());
+        if (bytes > v->lds_limit) continue;
+        // measured on MI355X (512^3 and 1024^3, 0..45 degrees): resident workgroups per CU matter more than lookahead depth
+        // inside one workgroup, and a deeper ring or a smaller tile never paid off: configurations are listed in order of
+        // preference and the first that fits wins unless VT_TILE forces one (planning is on the per-call path: keep it cheap)
+        c.plan->kind = 4; c.plan->cfg = cfg; c.plan->td = g; c.plan->th = th; c.plan->tw = tw;
+        c.plan->lds_bytes = (int)bytes;
+        p->Lz = ring; p->Ly = std::min(L[1], march_rows_max()); p->Lx = L[2]; p->Lx_used = lx_used4 ? lx_used4 : L[2];
+        p->slot_floats = slot_floats;
+        p->flags = (c.flags & VT_KEEP_OUTSIDE) | (march_box ? (1 << 20) : 0) | experiment_flags(v);
+        return true;
+    }
+    return false;
+}
+
+bool plan_march(PlanCtx& c)
+{
+    const vt_volume* v = c.v;
+    AffineParams* p = c.p;
+    TilePlan* plan = c.plan;
+    if (!c.zsep || (c.flags & VT_NO_MARCH) || (int64_t)v->H * v->P * 4 >= 0x7fffffffLL) return false;
+    const TilePlan saved = *plan;
+    if (!march_pick_tile(c)) return false;
+    const int T[3] = {1, plan->th, plan->tw};
+    set_tile_reach(p, c.m, T, 1);
+    set_axis0_split(p, c.m);
+    p->nTh = (v->oH + plan->th - 1) / plan->th;
+    p->nTw = (v->oW + plan->tw - 1) / plan->tw;
+    const int g = plan->td;
+    const int64_t inplane = (int64_t)p->nTh * p->nTw;
+    // short chunks keep the workgroups that share source rows (in-plane neighbours) at nearby planes, so the
+    // overlap of their boxes is served by the XCD's L2 instead of the fabric (measured: 1024^3 linear
+    // 3.4 ms at 342 planes per chunk, 2.1 ms at 16); the cubic kernels pay 5 planes of prologue per chunk
+    // [measured, 0 and 45 degrees] linear (packed spans): 16 planes at both 512^3 and 1024^3; cubic (boxes): 64 planes
+    // at 512^3 (0.379 vs 0.387 ms), 32 at 1024^3 (2.80 vs 2.88 ms)
+    const int target_dch = c.cubic ? (((int64_t)v->H * v->W <= 512 * 512) ? 64 : 32) : 16;
+    int64_t nchunks = std::max<int64_t>(1, (v->oD + target_dch - 1) / target_dch);
+    // small volumes: shorter chunks until the launch has ~4 workgroups per CU, not below 4 planes per chunk
+    nchunks = std::max(nchunks, std::min<int64_t>((4 * (int64_t)v->cu_count + inplane - 1) / inplane, (v->oD + 3) / 4));
+    // the chunk's planes are addressed with a 31-bit scalar byte offset from its first plane
+    const int64_t plane_bytes = (int64_t)v->H * v->P * 4;
+    const int64_t n_addr = ((int64_t)v->oD * plane_bytes) / 0x60000000LL + 1;
+    nchunks = std::max<int64_t>(nchunks, n_addr);
+    // (no round-aware chunk count here: [measured] the linear kernel loses more L2 sharing with deeper chunks than
+    // it gains from whole rounds -- 512^3 0.250 vs 0.220 ms, 640^3 0.442 vs 0.419)
+    if (v->tune.dch > 0) nchunks = std::max<int64_t>(1, (v->oD + v->tune.dch - 1) / v->tune.dch);
+    int dch = (int)((v->oD + nchunks - 1) / nchunks);
+    dch = ((dch + g - 1) / g) * g;
+    nchunks = (v->oD + dch - 1) / dch;
+    p->dch = dch;
+    p->nTd = (int)nchunks;
+    if (v->tune.blk_h > 0 && v->tune.blk_w > 0) { p->blk_h = v->tune.blk_h; p->blk_w = v->tune.blk_w; }
+    const int64_t grid = inplane * nchunks;
+    if (grid > 0x7fffffffLL) { *plan = saved; return false; }
+    plan->grid = (int)grid;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// box: 3-D tiles, bounding box of the footprint staged (kinds 2, 3)
+// ---------------------------------------------------------------------------------------------------
+// Picks the tile with the fewest staged bytes per output voxel; *bpv = that figure (the packed family compares against it).
+bool pick_box_tile(PlanCtx& c, double* bpv)
+{
+    const vt_volume* v = c.v;
+    const double* m = c.m;
+    double best_cost = 1e300;
+    bool found = false;
+    for (int cfg = 0; cfg < tile_config_count(); ++cfg) {
+        if (v->tune.tile >= 0 && cfg != v->tune.tile) continue;
+        int T[3];
+        tile_config(cfg, &T[0], &T[1], &T[2]);
+        int L[3];
+        bool ok = true;
+        for (int r = 0; r < 3 && ok; ++r) {
+            double ext = 0;
+            for (int k = 0; k < 3; ++k) ext += std::fabs(m[4 * r + k]) * (T[k] - 1);
+            if (!(ext < 4096.0)) { ok = false; break; }
+            L[r] = (int)std::floor(ext) + 3 + c.halo2;       // floor(hi)-floor(lo) <= floor(ext)+1, +1 upper tap, +1 slack
+        }
+        if (!ok) continue;
+        if (c.zsep) L[0] = T[0] + 1 + c.halo2;               // exactly the planes d0+zoff-halo .. d0+TD+zoff+halo
+        L[2] = (L[2] + 3 + 3) & ~3;                          // origin aligned down by up to 3, stride multiple of 4
+        const int64_t bytes = (int64_t)L[0] * L[1] * L[2] * 4;
+        if (bytes > v->lds_limit) continue;
+        const int blocks_per_cu = (int)std::min<int64_t>(8, (160 * 1024) / bytes);
+        const double vox = (double)T[0] * T[1] * T[2];
+        // staged bytes per output voxel, penalised when fewer than 3 workgroups fit a CU (no overlap of
+        // one workgroup's staging with another's gather)
+        const double cost = (double)bytes / vox * (blocks_per_cu >= 3 ? 1.0 : (blocks_per_cu == 2 ? 1.25 : 2.0));
+        if (cost < best_cost) {
+            best_cost = cost;
+            *bpv = (double)bytes / vox;
+            c.plan->kind = c.zsep ? 3 : 2; c.plan->cfg = cfg; c.plan->td = T[0]; c.plan->th = T[1]; c.plan->tw = T[2];
+            c.plan->lds_bytes = (int)bytes;
+            c.p->Lz = L[0]; c.p->Ly = L[1]; c.p->Lx = L[2];
+            found = true;
+        }
+    }
+    return found;
+}
+
+bool finish_box(PlanCtx& c)
+{
+    const vt_volume* v = c.v;
+    AffineParams* p = c.p;
+    TilePlan* plan = c.plan;
+    if (c.zsep) set_axis0_split(p, c.m);
+    const int T[3] = {plan->td, plan->th, plan->tw};
+    set_tile_reach(p, c.m, T, 0);
+    p->nTd = (v->oD + T[0] - 1) / T[0];
+    p->nTh = (v->oH + T[1] - 1) / T[1];
+    p->nTw = (v->oW + T[2] - 1) / T[2];
+    const int64_t grid = (int64_t)p->nTd * p->nTh * p->nTw;
+    if (grid > 0x7fffffffLL) return false;
+    plan->grid = (int)grid;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// packed: 3-D tiles, packed row spans of the footprint staged, persistent workgroups (kind 6)
+// ---------------------------------------------------------------------------------------------------
+struct PackedChoice { TilePlan plan; AffineParams p; double bpv; bool found; };
+
+bool invert3(const double m[12], double inv[9])
+{
+    const double A[9] = {m[0], m[1], m[2], m[4], m[5], m[6], m[8], m[9], m[10]};
+    const double det = A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6]) + A[2] * (A[3] * A[7] - A[4] * A[6]);
+    double amax = 0;
+    for (double a : A) amax = std::max(amax, std::fabs(a));
+    if (!(std::fabs(det) > 1e-6 * amax * amax * amax && amax < 64.0)) return false;
+    const double id = 1.0 / det;
+    const double r[9] = {(A[4] * A[8] - A[5] * A[7]) * id, (A[2] * A[7] - A[1] * A[8]) * id, (A[1] * A[5] - A[2] * A[4]) * id,
+                         (A[5] * A[6] - A[3] * A[8]) * id, (A[0] * A[8] - A[2] * A[6]) * id, (A[2] * A[3] - A[0] * A[5]) * id,
+                         (A[3] * A[7] - A[4] * A[6]) * id, (A[1] * A[6] - A[0] * A[7]) * id, (A[0] * A[4] - A[1] * A[3]) * id};
+    for (int i = 0; i < 9; ++i) inv[i] = r[i];
+    return true;
+}
+
+void pick_packed_tile(PlanCtx& c, const double inv[9], PackedChoice* out)
+{
+    const vt_volume* v = c.v;
+    const double* m = c.m;
+    double best = 1e300;
+    out->found = false;
+    for (int cfg = 0; cfg < packed_config_count(); ++cfg) {
+        if (v->tune.tile >= 0 && cfg != v->tune.tile) continue;
+        int T[3];
+        packed_config(cfg, &T[0], &T[1], &T[2]);
+        // too few tiles to amortise the per-workgroup set-up (see `enough` in plan_packed): do not even plan it -- the span
+        // summation below is the most expensive part of the host-side planning (~20 us)
+        const int64_t tiles_c = (int64_t)((v->oD + T[0] - 1) / T[0]) * ((v->oH + T[1] - 1) / T[1]) * ((v->oW + T[2] - 1) / T[2]);
+        if (!(c.flags & VT_FORCE_PACKED) && tiles_c < 6 * (int64_t)v->cu_count * (c.cubic ? 2 : 3)) continue;
+        PackGeom g;
+        int L[3];
+        bool ok = true;
+        double neg[3], pos[3];
+        for (int r = 0; r < 3 && ok; ++r) {
+            double ext = 0;
+            neg[r] = pos[r] = 0;
+            for (int k = 0; k < 3; ++k) {
+                const double e = m[4 * r + k] * (T[k] - 1);
+                ext += std::fabs(e);
+                if (e < 0) neg[r] += e; else pos[r] += e;
+            }
+            if (!(ext < 1000.0)) { ok = false; break; }
+            g.ext[r] = ext;
+            L[r] = (int)std::floor(ext) + 3 + c.halo2;
+        }
+        if (!ok) continue;
+        L[2] = (L[2] + 3 + 3) & ~3;
+        const int rows = L[0] * L[1];
+        if (rows > packed_rows_max() || L[2] > 4000) continue;
+        for (int i = 0; i < 9; ++i) g.inv[i] = inv[i];
+        for (int cc = 0; cc < 3; ++cc) g.cst[cc] = inv[3 * cc] * neg[0] + inv[3 * cc + 1] * neg[1] + inv[3 * cc + 2] * neg[2];
+        g.T[0] = T[0]; g.T[1] = T[1]; g.T[2] = T[2];
+        g.halo = c.cubic ? 1 : 0;
+        g.Lxbox = L[2];
+        g.Lybox = L[1];
+        int nvec = 0;
+        for (int row = 0; row < rows; ++row) {
+            int mn, mx;
+            if (packed_row_span(g, row / L[1], row % L[1], &mn, &mx)) nvec += ((mx - (mn & ~3)) >> 2) + 1;
+        }
+        const int cap_vec = nvec + rows / 16 + 8;                 // margin for host/device rounding differences
+        if (cap_vec > packed_vectors_max()) continue;
+        const int table_floats = (2 * rows + 8 + 3) & ~3;
+        const int64_t bytes = ((int64_t)table_floats + (int64_t)cap_vec * 4) * 4;
+        if (bytes > v->lds_limit) continue;
+        const int blocks_per_cu = (int)std::min<int64_t>(c.cubic ? 2 : 3, (160 * 1024) / bytes);   // VGPR-limited occupancy
+        const double vox = (double)T[0] * T[1] * T[2];
+        const double cost = (double)bytes / vox * (blocks_per_cu >= 3 ? 1.0 : (blocks_per_cu == 2 ? 1.2 : 2.0));
+        if (cost < best) {
+            best = cost;
+            out->found = true;
+            out->bpv = (double)bytes / vox;
+            out->plan.kind = 6; out->plan.cfg = cfg; out->plan.td = T[0]; out->plan.th = T[1]; out->plan.tw = T[2];
+            out->plan.lds_bytes = (int)bytes;
+            out->p.Lz = L[0]; out->p.Ly = L[1]; out->p.Lx = cap_vec * 4;
+            out->p.slot_floats = table_floats;
+            for (int r = 0; r < 3; ++r) { out->p.neg[r] = neg[r]; out->p.pos[r] = pos[r]; }
+            out->plan.geo = g;
+            out->plan.blocks_per_cu = blocks_per_cu;
+        }
+    }
+}
+
+// General matrices: packed 3-D footprints when the linear part is invertible.  Bounding boxes are cheaper to address (no row
+// table), so the packed form must stage clearly less to win: measured cross-over at ~0.6x of the box bytes per voxel for
+// trilinear (512^3).  Cubic: both kernels gather with 8-byte reads and the boxes win at every size ([measured]
+// rotation (25,-40,70): 250^3 0.177 vs 0.198 ms, 384^3 0.563 vs 0.604, 512^3 1.295 vs 1.328), so the packed form is only planned
+// for trilinear (or when forced).  `have_box`: a box plan is already in *c.plan with box_bpv staged bytes per voxel.
+bool plan_packed(PlanCtx& c, bool have_box, double box_bpv)
+{
+    const vt_volume* v = c.v;
+    if (c.zsep || (c.flags & VT_NO_PACKED) || (c.cubic && !(c.flags & VT_FORCE_PACKED))) return false;
+    double inv[9];
+    if (!invert3(c.m, inv)) return false;
+    PackedChoice pk;
+    pk.plan = *c.plan;
+    pk.p = *c.p;
+    pick_packed_tile(c, inv, &pk);
+    if (!pk.found) return false;
+    const bool forced = (c.flags & VT_FORCE_PACKED) != 0;
+    // every persistent workgroup pays ~20 us to build its span table and staging descriptors: worth it only when it
+    // then walks several tiles (measured: boxes win up to 250^3, on par at 320^3, packed 1.5x ahead at 512^3)
+    const int64_t pk_tiles = (int64_t)((v->oD + pk.plan.td - 1) / pk.plan.td) * ((v->oH + pk.plan.th - 1) / pk.plan.th) *
+                             ((v->oW + pk.plan.tw - 1) / pk.plan.tw);
+    const bool enough = pk_tiles >= 6 * (int64_t)v->cu_count * std::max(1, pk.plan.blocks_per_cu);
+    if (!(!have_box || forced || (enough && pk.bpv < (c.cubic ? 0.5 : 0.6) * box_bpv))) return false;
+    *c.plan = pk.plan;
+    *c.p = pk.p;
+    AffineParams* p = c.p;
+    p->nTd = (v->oD + pk.plan.td - 1) / pk.plan.td;
+    p->nTh = (v->oH + pk.plan.th - 1) / pk.plan.th;
+    p->nTw = (v->oW + pk.plan.tw - 1) / pk.plan.tw;
+    const int64_t ntiles = (int64_t)p->nTd * p->nTh * p->nTw;
+    if (ntiles > 0x7fffffffLL) { c.plan->kind = 1; return true; }      // (as before: such a launch goes to the direct kernel)
+    // persistent workgroups: as many as stay resident, a multiple of 8 (one share per XCD)
+    if (v->tune.plain_tile_order) p->flags |= (1 << 23);
+    int64_t nwg = std::min<int64_t>(ntiles, (int64_t)v->cu_count * std::max(1, c.plan->blocks_per_cu));
+    nwg = std::max<int64_t>(8, (nwg + 7) / 8 * 8);
+    c.plan->grid = (int)nwg;
+    return true;
+}
+
+// box and packed compete on staged bytes per voxel
+bool plan_general(PlanCtx& c)
+{
+    double box_bpv = 1e300;
+    const bool have_box = pick_box_tile(c, &box_bpv);
+    if (plan_packed(c, have_box, box_bpv)) return true;
+    if (!have_box) return false;
+    if (!finish_box(c)) { c.plan->kind = 1; }
+    return true;
+}
+
+typedef bool (*plan_fn)(PlanCtx&);
+struct Family { const char* name; plan_fn plan; };
+const Family kFamilies[] = {
+    {"quad", plan_quad},        // axis-0-separable, plane-quad layout
+    {"zpair", plan_zpair},      // axis-0-separable cubic, plane-pair layout
+    {"march", plan_march},      // axis-0-separable, plain layout
+    {"general", plan_general},  // 3-D tiles: bounding boxes vs packed footprints
+};
+
+}  // namespace
+
+void plan_launch(const vt_volume* v, const double m[12], int flags, AffineParams* p, TilePlan* plan)
+{
+    const int64_t n_out = (int64_t)v->oD * v->oH * v->oW;
+    std::memcpy(p->m, m, sizeof(double) * 12);
+    p->sD = v->D; p->sH = v->H; p->sW = v->W; p->sP = v->P;
+    for (int r = 0; r < 3; ++r) {
+        // Q32.32 split of the depth-axis step m[r][0] (|m| < 4096 is checked per family for tiled launches)
+        const double step = m[4 * r];
+        const double fl = std::floor(step);
+        p->inc_hi[r] = (std::fabs(step) < 2.0e9) ? (int32_t)fl : 0;
+        p->inc_lo[r] = (uint32_t)std::min(4294967295.0, std::floor((step - fl) * 4294967296.0 + 0.5));
+        if ((step - fl) * 4294967296.0 + 0.5 >= 4294967296.0) { p->inc_lo[r] = 0; p->inc_hi[r] += 1; }
+    }
+    p->oD = v->oD; p->oH = v->oH; p->oW = v->oW;
+    p->ostride = (int64_t)v->oH * v->oW; p->orow = v->oW;
+    p->ord[0] = 0; p->ord[1] = 1; p->ord[2] = 2;
+    p->ia1 = march_recip(m[5]); p->ib1 = march_recip(m[6]);
+    p->flags = (flags & VT_KEEP_OUTSIDE);
+    // skirt rule src + 0.5 in [0, dim) on the global volume, expressed on resident coordinates
+    p->vlo[0] = -0.5 - (double)v->plane0;  p->vhi[0] = (double)v->gD - 0.5 - (double)v->plane0;
+    p->vlo[1] = -0.5;                      p->vhi[1] = (double)v->H - 0.5;
+    p->vlo[2] = -0.5;                      p->vhi[2] = (double)v->W - 0.5;
+    p->zero_off = ((v->W + 3) & ~3) * 4;
+
+    plan->kind = 1; plan->cfg = -1; plan->td = plan->th = plan->tw = 0; plan->lds_bytes = 0; plan->grid = 0;
+    bool want_tiled = n_out >= 64 * 64 * 64;
+    if (flags & VT_FORCE_TILED) want_tiled = true;
+    if (flags & VT_FORCE_DIRECT) want_tiled = false;
+    if (!want_tiled) return;
+
+    PlanCtx c;
+    c.v = v; c.m = m; c.flags = flags; c.p = p; c.plan = plan;
+    c.cubic = is_cubic(v->interp);
+    c.halo2 = c.cubic ? 2 : 0;           // cubic taps reach one voxel further on each side
+    c.zsep = !(flags & VT_NO_ZSEP) && m[0] == 1.0 && m[1] == 0.0 && m[2] == 0.0 && m[4] == 0.0 && m[8] == 0.0 && std::fabs(m[3]) < 1.0e9;
+    for (const Family& f : kFamilies)
+        if (f.plan(c)) return;
+    plan->kind = 1;                       // nothing tiled fits: direct gather
+}
+
+}  // namespace vt
