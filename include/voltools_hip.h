@@ -63,7 +63,9 @@ enum vt_flags {
 enum vt_create_flags {
     VT_SRC_DEVICE = 1,       /* `data` is a device pointer on `dev` (else host memory)                    */
     VT_SLAB_LO_INTERIOR = 2, /* slab volumes: plane 0 of `data` is NOT the global volume's first plane     */
-    VT_SLAB_HI_INTERIOR = 4  /* slab volumes: the last plane of `data` is NOT the global volume's last     */
+    VT_SLAB_HI_INTERIOR = 4, /* slab volumes: the last plane of `data` is NOT the global volume's last     */
+    VT_SRC_DEFERRED = 8      /* `data` may be NULL: the resident window starts zero-filled, is filled plane range by plane
+                                range with vt_volume_upload_planes and becomes usable with vt_volume_finalize              */
 };
 
 enum vt_error {
@@ -126,6 +128,13 @@ int vt_volume_create_slab(int dev, int local_depth, int height, int width, int i
                           const float* data, int create_flags,
                           int64_t plane0, int64_t global_depth, int64_t out_plane0, int out_depth,
                           vt_volume_t** out);
+
+/* Deferred construction (multi-GPU slabs: a rank's own planes and the halo planes it receives from its neighbours land in
+ * the resident buffer directly, without assembling the window in a second device buffer first).  No reference counterpart.
+ * `data`: nplanes * height * width float32 (host, or device with VT_SRC_DEVICE in `flags`) for resident planes
+ * [first_plane, first_plane + nplanes).  vt_volume_finalize runs the one-time prefilter (filt_*) and enables the handle. */
+int vt_volume_upload_planes(vt_volume_t* vol, int first_plane, int nplanes, const float* data, int flags);
+int vt_volume_finalize(vt_volume_t* vol);
 
 int vt_volume_destroy(vt_volume_t* vol);
 int vt_volume_info(const vt_volume_t* vol, vt_volume_info_t* info);

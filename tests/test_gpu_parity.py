@@ -637,6 +637,59 @@ def test_slab_handles_reproduce_whole_volume(interp):
             assert np.abs(sum(prs) - want.astype(np.float64).sum(axis=0)).max() <= tol * G, (interp, flags, 'projection')
 
 
+@pytest.mark.parametrize('interp', ['linear', 'filt_bspline'])
+def test_deferred_handle_upload_planes_finalize(interp):
+    """VT_SRC_DEFERRED / vt_volume_upload_planes / vt_volume_finalize (the construction path of SlabVolume): a window filled plane
+    range by plane range, from host and from device memory, equals the handle built from the assembled window; planes never
+    uploaded read as zeros; the handle refuses transforms before it is finalized and uploads after."""
+    import ctypes
+    lib = _native.load()
+    D, H, W = 44, 40, 50
+    vol = rand_vol((D, H, W), 31)
+    m = np.ascontiguousarray(vt.utils.transform_matrix(rotation=(0, 33, 0), translation=(0.5, 1.5, -2.0), center=centre((D, H, W))), dtype=np.float32)
+    code = _native.INTERP_CODES[interp]
+
+    def run(handle):
+        out = np.empty((D, H, W), np.float32)
+        _native.check(lib.vt_volume_affine(handle, m.ctypes.data, out.ctypes.data, _native.FORCE_TILED), 'affine')
+        return out
+
+    ref_h = ctypes.c_void_p()
+    _native.check(lib.vt_volume_create(0, D, H, W, code, vol.ctypes.data, 0, ctypes.byref(ref_h)), 'create')
+    want = run(ref_h)
+    lib.vt_volume_destroy(ref_h)
+
+    h = ctypes.c_void_p()
+    _native.check(lib.vt_volume_create_slab(0, D, H, W, code, None, _native.SRC_DEFERRED, 0, D, 0, D, ctypes.byref(h)), 'create deferred')
+    out = np.empty((D, H, W), np.float32)
+    assert lib.vt_volume_affine(h, m.ctypes.data, out.ctypes.data, 0) != 0            # not finalized yet
+    a = np.ascontiguousarray(vol[10:30])
+    _native.check(lib.vt_volume_upload_planes(h, 10, 20, a.ctypes.data, 0), 'upload host')
+    dev = _native.DeviceArray.from_numpy(np.ascontiguousarray(vol[:10]), 0)
+    _native.check(lib.vt_volume_upload_planes(h, 0, 10, ctypes.c_void_p(dev.ptr), _native.SRC_DEVICE), 'upload device')
+    b = np.ascontiguousarray(vol[30:])
+    _native.check(lib.vt_volume_upload_planes(h, 30, D - 30, b.ctypes.data, 0), 'upload host 2')
+    assert lib.vt_volume_upload_planes(h, 40, 10, b.ctypes.data, 0) != 0               # beyond the window
+    _native.check(lib.vt_volume_finalize(h), 'finalize')
+    assert lib.vt_volume_upload_planes(h, 0, 1, a.ctypes.data, 0) != 0                 # finalized: no more uploads
+    got = run(h)
+    lib.vt_volume_destroy(h)
+    dev.free()
+    assert np.array_equal(got, want)
+
+    # planes that were never uploaded are zeros
+    h = ctypes.c_void_p()
+    _native.check(lib.vt_volume_create_slab(0, D, H, W, code, None, _native.SRC_DEFERRED, 0, D, 0, D, ctypes.byref(h)), 'create deferred')
+    _native.check(lib.vt_volume_upload_planes(h, 10, 20, a.ctypes.data, 0), 'upload host')
+    _native.check(lib.vt_volume_finalize(h), 'finalize')
+    got = run(h)
+    lib.vt_volume_destroy(h)
+    holes = vol.copy()
+    holes[:10] = 0
+    holes[30:] = 0
+    assert np.abs(got - oracle.affine(holes, m, interp)).max() <= TOL[interp]
+
+
 @pytest.mark.timeout(300, method='thread')     # an RCCL bring-up that hangs on a bad box must not hold the whole run
 def test_slab_volume_single_rank_process_group():
     """The product multi-GPU class end to end on one rank (RCCL process group of size 1).  Kept last in this file."""

@@ -19,14 +19,14 @@ INTERP_CODES = {'linear': 0, 'bspline': 1, 'bspline_simple': 2, 'filt_bspline': 
 # enum vt_flags
 OUT_DEVICE, KEEP_OUTSIDE, FORCE_DIRECT, FORCE_TILED, NO_ZSEP, NO_MARCH, NO_ZPAIR, NO_PACKED, FORCE_PACKED, FORCE_XSWAP, NO_RSWAP, NO_QUAD = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048
 # enum vt_create_flags
-SRC_DEVICE, SLAB_LO_INTERIOR, SLAB_HI_INTERIOR = 1, 2, 4
+SRC_DEVICE, SLAB_LO_INTERIOR, SLAB_HI_INTERIOR, SRC_DEFERRED = 1, 2, 4, 8
 
 # every symbol include/voltools_hip.h declares (tests check the library exports all of them)
 SYMBOLS = [
     'vt_device_count', 'vt_device_name', 'vt_device_props', 'vt_device_synchronize',
     'vt_malloc', 'vt_free', 'vt_memset_zero', 'vt_memcpy_h2d', 'vt_memcpy_d2h', 'vt_memcpy_d2d',
     'vt_host_register', 'vt_host_unregister', 'vt_device_trim',
-    'vt_volume_create', 'vt_volume_create_slab', 'vt_volume_destroy', 'vt_volume_info', 'vt_volume_stream',
+    'vt_volume_create', 'vt_volume_create_slab', 'vt_volume_upload_planes', 'vt_volume_finalize', 'vt_volume_destroy', 'vt_volume_info', 'vt_volume_stream',
     'vt_volume_sync', 'vt_volume_set_output_shape', 'vt_volume_affine', 'vt_volume_affine_f64',
     'vt_volume_project', 'vt_volume_project_f64', 'vt_volume_affine_batch',
     'vt_timer_start', 'vt_timer_stop', 'vt_prefilter_inplace', 'vt_affine_oneshot',
@@ -97,6 +97,8 @@ def load():
     L.vt_volume_create.argtypes = [c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, P(c_void_p)]
     L.vt_volume_create_slab.argtypes = [c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                         c_i64, c_i64, c_i64, c_int, P(c_void_p)]
+    L.vt_volume_upload_planes.argtypes = [c_void_p, c_int, c_int, c_void_p, c_int]
+    L.vt_volume_finalize.argtypes = [c_void_p]
     L.vt_volume_destroy.argtypes = [c_void_p]
     L.vt_volume_info.argtypes = [c_void_p, P(VolumeInfo)]
     L.vt_volume_stream.argtypes = [c_void_p, P(c_void_p)]

@@ -575,6 +575,7 @@ int host_output_buffer(vt_volume* v, size_t n_elems, float** d_out)
 int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
 {
     if (!v || !m4x4 || !out) return fail(VT_EINVAL, "NULL argument");
+    if (v->deferred) return fail(VT_EINVAL, "handle was created with VT_SRC_DEFERRED and has not been finalized (vt_volume_finalize)");
     int rc = use_device(v->dev);
     if (rc) return rc;
     (void)hipGetLastError();                      // a stale sticky error of an unrelated call must not fail this launch's check
@@ -620,12 +621,46 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
 
 constexpr int kSrcNone = 1 << 30;   // internal create flag: no source data (zero-filled resident buffer)
 
+// Last step of building a handle: the one-time prefilter of filt_* interpolations over the resident samples
+// (transforms.py:195-197, volume.py:48-50), then the handle is usable.
+int finalize_resident(vt_volume* v, bool lo_interior)
+{
+    const int dev = v->dev;
+    if (is_filtered(v->interp)) {
+        const size_t bytes = v->src_bytes;
+        float* d_tmp = nullptr;
+        VT_HIP(cached_malloc(dev, reinterpret_cast<void**>(&d_tmp), bytes));
+        {
+            hipError_t em = hipMemset2DAsync(d_tmp + v->W, (size_t)v->P * sizeof(float), 0, (size_t)(v->P - v->W) * sizeof(float),
+                                             (size_t)v->D * v->H, v->stream);
+            if (em != hipSuccess) { cached_free(dev, d_tmp, bytes); return fail((int)em, "memset: %s", hipGetErrorString(em)); }
+        }
+        float* res = nullptr;
+        hipEventRecord(v->ev0, v->stream);
+        int rc = run_prefilter(v->d_src, d_tmp, v->D, v->H, v->W, v->P, lo_interior, v->stream, &res);
+        hipEventRecord(v->ev1, v->stream);
+        hipError_t es = hipStreamSynchronize(v->stream);
+        if (rc || es != hipSuccess) {
+            cached_free(dev, d_tmp, bytes);
+            if (!rc) rc = fail((int)es, "prefilter: %s", hipGetErrorString(es));
+            return rc;
+        }
+        hipEventElapsedTime(&v->prefilter_ms, v->ev0, v->ev1);
+        if (res == d_tmp) { cached_free(dev, v->d_src, bytes); v->d_src = d_tmp; }
+        else cached_free(dev, d_tmp, bytes);
+    } else {
+        VT_HIP(hipStreamSynchronize(v->stream));
+    }
+    v->deferred = false;
+    return 0;
+}
+
 int create_common(int dev, int D, int H, int W, int interp, const float* data, int cflags,
                   int64_t plane0, int64_t gD, int64_t out_plane0, int oD, vt_volume_t** out)
 {
     if (!out) return fail(VT_EINVAL, "NULL handle pointer");
     *out = nullptr;
-    if (!data && !(cflags & kSrcNone)) return fail(VT_EINVAL, "NULL data pointer");
+    if (!data && !(cflags & (kSrcNone | VT_SRC_DEFERRED))) return fail(VT_EINVAL, "NULL data pointer");
     if (D <= 0 || H <= 0 || W <= 0 || oD <= 0) return fail(VT_EINVAL, "non-positive dims (%d,%d,%d) out depth %d", D, H, W, oD);
     if (interp < VT_LINEAR || interp > VT_FILT_BSPLINE_SIMPLE) return fail(VT_EINVAL, "unknown interpolation code %d", interp);
     if ((int64_t)D * H > 0x7fffffffLL || (int64_t)H * W > 0x7fffffffLL) return fail(VT_EUNSUPPORTED, "plane count/size exceeds 2^31");
@@ -670,10 +705,13 @@ int create_common(int dev, int D, int H, int W, int interp, const float* data, i
     VT_HIPC(cached_malloc(dev, reinterpret_cast<void**>(&v->d_src), bytes));
     v->src_bytes = bytes;
     const hipMemcpyKind kind = (cflags & VT_SRC_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    if (cflags & kSrcNone) {
-        // internal helper volumes: zero-filled, written by a kernel later
+    if (cflags & (kSrcNone | VT_SRC_DEFERRED)) {
+        // internal helper volumes (written by a kernel later) and deferred handles (filled by vt_volume_upload_planes, made
+        // usable by vt_volume_finalize): zero-filled -- planes that are never uploaded read as the border colour
         VT_HIPC(hipMemsetAsync(v->d_src, 0, bytes, v->stream));
         VT_HIPC(hipStreamSynchronize(v->stream));
+        v->deferred = (cflags & VT_SRC_DEFERRED) != 0;
+        v->lo_interior = (cflags & VT_SLAB_LO_INTERIOR) != 0;
         *out = v;
         return 0;
     }
@@ -686,29 +724,8 @@ int create_common(int dev, int D, int H, int W, int interp, const float* data, i
         VT_HIPC(hipStreamSynchronize(v->stream));
     }
 
-    if (is_filtered(interp)) {
-        float* d_tmp = nullptr;
-        VT_HIPC(cached_malloc(dev, reinterpret_cast<void**>(&d_tmp), bytes));
-        {
-            hipError_t em = hipMemset2DAsync(d_tmp + W, (size_t)v->P * sizeof(float), 0, (size_t)(v->P - W) * sizeof(float), (size_t)D * H, v->stream);
-            if (em != hipSuccess) { cached_free(dev, d_tmp, bytes); return cleanup(fail((int)em, "memset: %s", hipGetErrorString(em))); }
-        }
-        float* res = nullptr;
-        hipEventRecord(v->ev0, v->stream);
-        rc = run_prefilter(v->d_src, d_tmp, D, H, W, v->P, (cflags & VT_SLAB_LO_INTERIOR) != 0, v->stream, &res);
-        hipEventRecord(v->ev1, v->stream);
-        hipError_t es = hipStreamSynchronize(v->stream);
-        if (rc || es != hipSuccess) {
-            cached_free(dev, d_tmp, bytes);
-            if (!rc) rc = fail((int)es, "prefilter: %s", hipGetErrorString(es));
-            return cleanup(rc);
-        }
-        hipEventElapsedTime(&v->prefilter_ms, v->ev0, v->ev1);
-        if (res == d_tmp) { cached_free(dev, v->d_src, bytes); v->d_src = d_tmp; }
-        else cached_free(dev, d_tmp, bytes);
-    } else {
-        VT_HIPC(hipStreamSynchronize(v->stream));
-    }
+    rc = finalize_resident(v, (cflags & VT_SLAB_LO_INTERIOR) != 0);
+    if (rc) return cleanup(rc);
 #undef VT_HIPC
     *out = v;
     return 0;
@@ -908,6 +925,7 @@ int oneshot_pipelined(int dev, const float* h_volume, int D, int H, int W, int i
 int do_affine_batch(vt_volume* v, int n, const double* m4x4s, float* out, int flags)
 {
     if (!v || !m4x4s || !out) return fail(VT_EINVAL, "NULL argument");
+    if (v->deferred) return fail(VT_EINVAL, "handle has not been finalized (vt_volume_finalize)");
     if (n <= 0) return fail(VT_EINVAL, "batch size %d", n);
     int rc = use_device(v->dev);
     if (rc) return rc;
@@ -978,6 +996,7 @@ int do_affine_batch(vt_volume* v, int n, const double* m4x4s, float* out, int fl
 int do_project(vt_volume* v, const double m4x4[16], float* out, int flags)
 {
     if (!v || !m4x4 || !out) return fail(VT_EINVAL, "NULL argument");
+    if (v->deferred) return fail(VT_EINVAL, "handle has not been finalized (vt_volume_finalize)");
     int rc = use_device(v->dev);
     if (rc) return rc;
     for (int i = 0; i < 12; ++i)
@@ -1221,6 +1240,32 @@ int vt_volume_create_slab(int dev, int local_depth, int height, int width, int i
 {
     return create_common(dev, local_depth, height, width, interp, data, create_flags,
                          plane0, global_depth, out_plane0, out_depth, out);
+}
+
+int vt_volume_upload_planes(vt_volume_t* v, int first_plane, int nplanes, const float* data, int flags)
+{
+    if (!v || !data) return fail(VT_EINVAL, "NULL argument");
+    if (!v->deferred) return fail(VT_EINVAL, "planes can only be uploaded into a handle created with VT_SRC_DEFERRED, before vt_volume_finalize");
+    if (first_plane < 0 || nplanes <= 0 || (int64_t)first_plane + nplanes > v->D)
+        return fail(VT_EINVAL, "planes [%d, %d) outside the resident window of %d planes", first_plane, first_plane + nplanes, v->D);
+    int rc = use_device(v->dev);
+    if (rc) return rc;
+    const bool src_dev = (flags & VT_SRC_DEVICE) != 0;
+    const size_t rows = (size_t)nplanes * v->H;
+    PinnedScope pin(src_dev ? nullptr : data, src_dev ? 0 : rows * v->W * sizeof(float));
+    VT_HIP(hipMemcpy2DAsync(v->d_src + (size_t)first_plane * v->H * v->P, (size_t)v->P * sizeof(float), data, (size_t)v->W * sizeof(float),
+                            (size_t)v->W * sizeof(float), rows, src_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, v->stream));
+    VT_HIP(hipStreamSynchronize(v->stream));
+    return 0;
+}
+
+int vt_volume_finalize(vt_volume_t* v)
+{
+    if (!v) return fail(VT_EINVAL, "NULL handle");
+    if (!v->deferred) return 0;
+    int rc = use_device(v->dev);
+    if (rc) return rc;
+    return finalize_resident(v, v->lo_interior);
 }
 
 int vt_volume_destroy(vt_volume_t* v)

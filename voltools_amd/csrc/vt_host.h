@@ -81,6 +81,8 @@ struct vt_volume {
     size_t proj_tmp_elems = 0;
     vt_volume* proj = nullptr;         // projection helper: 3 x H x W volume [S, S, S] sharing this handle's stream
     bool owns_stream = true;
+    bool deferred = false;             // created with VT_SRC_DEFERRED: planes still being uploaded, not usable before vt_volume_finalize
+    bool lo_interior = false;          // ... and its VT_SLAB_LO_INTERIOR flag, kept for the prefilter at finalize
     size_t scratch_elems = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

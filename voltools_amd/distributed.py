@@ -117,9 +117,18 @@ class SlabVolume:
         self._dev = switch_to_device(device) if on_gpu else -1
         tdev = torch.device('cuda', self._dev) if on_gpu else torch.device('cpu')
 
-        own = local if isinstance(local, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(local, dtype=np.float32))
-        own = own.to(device=tdev, dtype=torch.float32).contiguous()
-        S, H, W = (int(s) for s in own.shape)
+        # The HIP path keeps a host slab on the host: its planes go straight into the resident buffer (one pinned upload), and only
+        # the boundary planes a neighbour needs are staged as device tensors for the exchange.  The test engine (CPU ranks over
+        # gloo) and device-resident inputs work on a tensor of the whole slab.
+        host_slab = (engine is None) and not isinstance(local, torch.Tensor)
+        if host_slab:
+            own_np = np.ascontiguousarray(local, dtype=np.float32)
+            own = None
+            S, H, W = (int(s) for s in own_np.shape)
+        else:
+            own = local if isinstance(local, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(local, dtype=np.float32))
+            own = own.to(device=tdev, dtype=torch.float32).contiguous()
+            S, H, W = (int(s) for s in own.shape)
 
         # slab sizes and cross-rank shape check
         meta = torch.tensor([S, H, W], dtype=torch.int64, device=tdev)
@@ -137,11 +146,13 @@ class SlabVolume:
 
         (w0, w1), recvs, sends = plan_halo_exchange(counts, self.rank, self.halo)
         self.window = (w0, w1)
-        window = torch.zeros((w1 - w0, H, W), dtype=torch.float32, device=tdev)
-        window[self.g0 - w0:self.g1 - w0] = own
-        ops = []
-        for dst, a, b in sends:
-            ops.append(dist.P2POp(dist.isend, own[a - self.g0:b - self.g0].contiguous(), self._global_rank(dst), group))
+
+        def own_planes(a, b):                        # global planes [a, b) of this rank's slab as a device tensor
+            if own is not None:
+                return own[a - self.g0:b - self.g0].contiguous()
+            return torch.from_numpy(own_np[a - self.g0:b - self.g0]).to(tdev)
+
+        ops = [dist.P2POp(dist.isend, own_planes(a, b), self._global_rank(dst), group) for dst, a, b in sends]
         recv_bufs = []
         for src, a, b in recvs:
             buf = torch.empty((b - a, H, W), dtype=torch.float32, device=tdev)
@@ -151,31 +162,45 @@ class SlabVolume:
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
-        for buf, a, b in recv_bufs:
-            window[a - w0:b - w0] = buf
         if on_gpu:
             torch.cuda.synchronize(tdev)
 
         if engine is not None:
+            window = torch.zeros((w1 - w0, H, W), dtype=torch.float32, device=tdev)
+            window[self.g0 - w0:self.g1 - w0] = own
+            for buf, a, b in recv_bufs:
+                window[a - w0:b - w0] = buf
             self._engine = engine(window, w0, self.global_shape[0], self.g0, S, interpolation)
             self._handle = None
+            del window
         else:
             if not on_gpu:
                 raise ValueError("SlabVolume needs a GPU device (the HIP path has no CPU fallback)")
             self._engine = None
             self._lib = _native.load()
-            flags = _native.SRC_DEVICE
+            # deferred handle: the resident window starts zero-filled; own planes and received halos are copied into it plane
+            # range by plane range (no second buffer of the window's size), then the prefilter runs once over the whole window
+            flags = _native.SRC_DEFERRED
             if w0 > 0:
                 flags |= _native.SLAB_LO_INTERIOR
             if w1 < self.global_shape[0]:
                 flags |= _native.SLAB_HI_INTERIOR
             h = ctypes.c_void_p()
-            _native.check(self._lib.vt_volume_create_slab(self._dev, w1 - w0, H, W, _INTERPOLATIONS[interpolation],
-                                                          ctypes.c_void_p(window.data_ptr()), flags, w0,
+            _native.check(self._lib.vt_volume_create_slab(self._dev, w1 - w0, H, W, _INTERPOLATIONS[interpolation], None, flags, w0,
                                                           self.global_shape[0], self.g0, S, ctypes.byref(h)),
                           'vt_volume_create_slab')
             self._handle = h
-        del window
+            if own is not None:
+                _native.check(self._lib.vt_volume_upload_planes(h, self.g0 - w0, S, ctypes.c_void_p(own.data_ptr()), _native.SRC_DEVICE),
+                              'vt_volume_upload_planes')
+            else:
+                _native.check(self._lib.vt_volume_upload_planes(h, self.g0 - w0, S, ctypes.c_void_p(own_np.ctypes.data), 0),
+                              'vt_volume_upload_planes')
+            for buf, a, b in recv_bufs:
+                _native.check(self._lib.vt_volume_upload_planes(h, a - w0, b - a, ctypes.c_void_p(buf.data_ptr()), _native.SRC_DEVICE),
+                              'vt_volume_upload_planes')
+            _native.check(self._lib.vt_volume_finalize(h), 'vt_volume_finalize')
+        del recv_bufs
 
     def _global_rank(self, group_rank: int) -> int:
         import torch.distributed as dist
