@@ -36,6 +36,7 @@ def parse():
     ap.add_argument('--strong', action='store_true', help='strong scaling: ONE size^3 volume cut into axis-0 slabs over the '
                     'ranks (SURVEY 8d config 5); default is weak scaling, one size^3 slab per rank')
     ap.add_argument('--prewarm-ms', type=float, default=250.0, help='untimed launches for at least this long before the timed steps')
+    ap.add_argument('--no-extra-1024', action='store_true', help='skip the 1024^3 trilinear entry of `extra`')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target wall time of the CPU baseline sample')
     return ap.parse_args()
@@ -261,6 +262,35 @@ def main():
                            'achieved_GBps': round(algo_bytes / ms / 1e6, 1), 'frac_of_8TBps': round(algo_bytes / ms / 1e6 / 8000.0, 4),
                            'tile': list(svl.info().last_tile)}
         svl.close()
+        if n == 512 and not args.no_extra_1024:
+            # the north star's other number: trilinear transform of a 1024^3 volume (BASELINE.json north_star: ">= 70 % of peak HBM
+            # bandwidth"), same sweep; the volume is generated on the device (torch: plumbing) so this costs ~2 s
+            try:
+                g = torch.Generator(device=f'cuda:{local_rank}')
+                g.manual_seed(1024)
+                big = torch.rand((1024, 1024, 1024), dtype=torch.float32, device=f'cuda:{local_rank}', generator=g)
+                svb = vt.StaticVolume(big, interpolation='linear', device=dev)
+                outb = vt.empty((1024, 1024, 1024), device=dev)
+                cb = np.divide(np.subtract((1024, 1024, 1024), 1), 2, dtype=np.float32)
+                mb = [vt.utils.transform_matrix(rotation=(0, float(a), 0), rotation_units='deg', rotation_order='rzxz', center=cb)
+                      for a in range(0, 180, 6)]
+                for m_ in mb[:3]:
+                    svb.affine(m_, output=outb)
+                svb.synchronize()
+                svb.timer_start()
+                for m_ in mb:
+                    svb.affine(m_, output=outb)
+                msb = svb.timer_stop() / len(mb)
+                extra['linear_1024'] = {'kernel_ms': round(msb, 4), 'Mvoxels_per_s': round(1024 ** 3 / msb / 1e3, 1),
+                                        'achieved_GBps': round(8.0 * 1024 ** 3 / msb / 1e6, 1),
+                                        'frac_of_8TBps': round(8.0 * 1024 ** 3 / msb / 1e6 / 8000.0, 4),
+                                        'angles': '0..174 step 6 (30 launches)', 'tile': list(svb.info().last_tile), 'kernel': int(svb.info().last_kernel)}
+                svb.close()
+                outb.free()
+                del big
+                torch.cuda.empty_cache()
+            except Exception as e:  # pragma: no cover  (e.g. a smaller device)
+                extra['linear_1024'] = {'error': str(e)}
         pf_ms = float(info.prefilter_ms)
         if pf_ms > 0:
             # the first prefilter of a process also pays for loading its kernels; a second resident volume shows the

@@ -21,6 +21,8 @@ struct Tuning {
     bool exp_noload = false;
     bool exp_nolds = false;
     bool exp_noloop = false;
+    int quad_rows = -2;            // VT_QUAD_ROWS: -1 = rows packed back to back, 0..15 = force the row stride S of the bank-aware placement, -2 = planner
+    int quad_grid2d = 1;           // VT_QUAD_GRID2D=0: 1-D grid with XCD-contiguous ids over all chunks (round-2 A/B)
     int quad_nt = -1;              // VT_QUAD_NT: 1 / 0 = nontemporal / plain output stores of the plane-quad kernel, -1 = planner's choice
     void read()
     {
@@ -40,6 +42,8 @@ struct Tuning {
         exp_nolds = std::getenv("VT_EXP_NOLDS") != nullptr;
         exp_noloop = std::getenv("VT_EXP_NOLOOP") != nullptr;
         quad_nt = num("VT_QUAD_NT", -1);
+        quad_grid2d = num("VT_QUAD_GRID2D", 1);
+        quad_rows = num("VT_QUAD_ROWS", -2);
     }
 };
 

@@ -44,6 +44,8 @@ struct AffineParams {
     int blk_h, blk_w;          // marching kernels: blocked tile order inside a chunk layer (tiles per block; 0 = plain order)
     int32_t sPq;               // plane-quad layout: floats per quad-row (4 * positions per row)
     int32_t zero_off_q;        // plane-quad layout: byte offset of a zero vector inside any quad-plane
+    uint32_t nTw_magic, nTh_magic;   // plane-quad kernel, 2-D grid: floor(2^32 / n) + 1 -- (u * magic) >> 32 == u / n for u * n < 2^32
+    int32_t row_s;             // plane-quad kernel: bank-aware row starts, slot = column + row * row_s (mod 16); -1 = rows packed back to back
     int32_t dshift;            // plane-quad kernel: chunk c > 0 starts at output plane c*dch + dshift (0..3), chosen so that a chunk's first
                                // tap plane is the first plane of a quad (one quad step per chunk beyond its own planes instead of two)
 };
@@ -203,6 +205,7 @@ hipError_t launch_transpose02(const float* src, float* dst, int n0, int n1, int 
                               int64_t ds0, int64_t ds1, hipStream_t stream);
 hipError_t launch_relayout_swap01(const float* src, float* dst, int D, int H, int P, hipStream_t stream);
 // plane-quad marching kernel (vt_kernels_quad.hip)
+int quad_max_it();
 int quad_config_count();
 void quad_config(int idx, int* th, int* tw, int* nt);
 int quad_blocks_per_cu(int cfg, int interp, int lds_bytes);

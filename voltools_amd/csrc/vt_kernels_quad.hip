@@ -32,6 +32,8 @@ namespace vt {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+constexpr int kQuadMaxIt = 5;     // staging instructions per thread and quad: footprints (with row padding) up to 5 * NT vectors
+
 // plain [z][y][P] -> quad layout [z/4][y][Pq]: element (z, y, x) at 4x + (z & 3) of row ((z >> 2), y); positions W .. Wq-1
 // of every row stay zero (the border colour; the staging loads fetch position W of row 0 for every out-of-volume vector)
 __global__ __launch_bounds__(256) void relayout_zquad(const float* __restrict__ src, float* __restrict__ dst,
@@ -129,9 +131,24 @@ __global__ __launch_bounds__(NT) void affine_march4(const float* __restrict__ sr
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x;
-    const int t = xcd_contiguous(blockIdx.x, gridDim.x);
     int tw_i, th_i, chunk;
-    march_tile(p, t, th_i, tw_i, chunk);
+    if (p.flags & (1 << 29)) {
+        // 2-D grid: blockIdx.y = chunk, blockIdx.x = in-plane tile.  Workgroups are dispatched x-fastest, so each XCD gets a
+        // contiguous band of every chunk layer in turn: the chip works on one or two layers at a time (compact write stream,
+        // halos shared inside the band), and the tile decode needs one multiply-high instead of two integer divisions.
+        chunk = blockIdx.y;
+        const unsigned u = (unsigned)xcd_contiguous(blockIdx.x, gridDim.x);
+        if (p.flags & (1 << 24)) {                // h fastest (in-plane transposed copy)
+            tw_i = (int)__umulhi(u, p.nTh_magic);
+            th_i = (int)u - tw_i * p.nTh;
+        } else {
+            th_i = (int)__umulhi(u, p.nTw_magic);
+            tw_i = (int)u - th_i * p.nTw;
+        }
+    } else {
+        const int t = xcd_contiguous(blockIdx.x, gridDim.x);
+        march_tile(p, t, th_i, tw_i, chunk);
+    }
     const int h0 = th_i * TH, w0 = tw_i * TW;
     const int d_begin = chunk ? chunk * p.dch + p.dshift : 0;
     const int d_end = min((chunk + 1) * p.dch + p.dshift, p.oD);
@@ -208,7 +225,7 @@ __global__ __launch_bounds__(NT) void affine_march4(const float* __restrict__ sr
     // turns (min, max) per row into (span start, first vector) by a 64-entry prefix sum and writes each vector's row index.
     // (The first version computed the spans analytically in float64 on one wave, march_row_span -- 200 float64 operations on the
     // critical path of every workgroup while three waves waited; the host still sizes the slot with that superset.)
-    int voff[kMaxIt];                             // byte offset inside a quad-plane of each vector this thread stages
+    int voff[kQuadMaxIt];                         // byte offset inside a quad-plane of each vector this thread stages
     int q[NPIX][NR];                              // byte offset of the first tap of each tap row inside a ring slot
     int nvec;
     {
@@ -240,29 +257,55 @@ __global__ __launch_bounds__(NT) void affine_march4(const float* __restrict__ sr
             const bool used = mn <= mx;
             const int x0 = used ? mn : 0;
             const int nv = used ? (mx - mn + 1) : 0;
-            int incl = nv;
+            int first, pad = 0, total;
+            {
+                int incl = nv;
 #pragma unroll
-            for (int s2 = 1; s2 < 64; s2 <<= 1) {
-                const int up = __shfl_up(incl, s2);
-                if (lane >= s2) incl += up;
+                for (int s2 = 1; s2 < 64; s2 <<= 1) {
+                    const int up = __shfl_up(incl, s2);
+                    if (lane >= s2) incl += up;
+                }
+                first = incl - nv;
+                total = __shfl(incl, 63);
             }
-            const int first = incl - nv;
+            if (p.row_s >= 0) {
+                // Bank-aware row starts (cubic): row r starts at a slot = x0 + r * S (mod 16), i.e. the image behaves like a box
+                // with row stride S in the 16-slot bank space of ds_read_b128 while only the spans are stored.  The gaps (< 16
+                // vectors per row) are filled from the zero vector.  S comes from the host's model of the gather's lane groups
+                // (vt_plan.hip: quad_row_stride): [model] conflict cycles per read 2.2-2.9x -> 1.0-1.7x below 20 degrees, ~2x above.
+                // Placement is sequential in the row index: one scalar pass over the wave's lanes.  If the padded image does
+                // not fit the slot, the unpadded prefix sum above stays.
+                int pos = 0, first_p = 0, pad_p = 0;
+                const int S = p.row_s;
+                for (int r = 0; r < kRowsMax; ++r) {
+                    const int nv_r = __builtin_amdgcn_readlane(nv, r);
+                    if (nv_r == 0) continue;
+                    const int x0_r = __builtin_amdgcn_readlane(x0, r);
+                    const int gap = (x0_r + r * S - pos) & 15;
+                    pos += gap;
+                    if (lane == r) { first_p = pos; pad_p = gap; }
+                    pos += nv_r;
+                }
+                if (((pos + 63) & ~63) * 16 <= p.slot_floats * 4 && pos <= NT * kQuadMaxIt) { first = first_p; pad = pad_p; total = pos; }
+            }
             tab[lane] = x0;
             tab[kRowsMax + lane] = first;
-            if (lane == kRowsMax - 1) tab[2 * kRowsMax] = incl;
+            if (lane == 0) tab[2 * kRowsMax] = total;
             const int last = min(first + nv, kVrowCap);
+            for (int v = max(first - pad, 0); v < min(first, kVrowCap); ++v) vrow[v] = 255;
             for (int v = first; v < last; ++v) vrow[v] = (unsigned char)lane;
         }
         __syncthreads();
 #endif
         nvec = tab[2 * kRowsMax];
 #pragma unroll
-        for (int it = 0; it < kMaxIt; ++it) {
+        for (int it = 0; it < kQuadMaxIt; ++it) {
             const int v = tid + NT * it;
-            const int y = (v < nvec && v < kVrowCap) ? vrow[v] : 0;
-            const int cx = v - tab[kRowsMax + y];
-            const int gy = o1 + y, gx = o2 + tab[y] + cx;
-            const bool ok = (v < nvec) && (unsigned)gy < (unsigned)p.sH && (unsigned)gx < (unsigned)p.sW;
+            const int y = (v < nvec && v < kVrowCap) ? vrow[v] : 255;
+            const int yy = (y == 255) ? 0 : y;
+            const int cx = v - tab[kRowsMax + yy];
+            const int gy = o1 + yy, gx = o2 + tab[yy] + cx;
+            const bool ok = (y != 255) && (unsigned)gy < (unsigned)p.sH && (unsigned)gx < (unsigned)p.sW;
             voff[it] = ok ? (gy * p.sPq + 4 * gx) * 4 : p.zero_off_q;
         }
 #pragma unroll
@@ -278,7 +321,7 @@ __global__ __launch_bounds__(NT) void affine_march4(const float* __restrict__ sr
     const int nvec64 = (nvec + 63) & ~63;         // whole waves stage: a wave's instruction is issued in full or not at all
     const int slot_bytes = p.slot_floats * 4;
 
-    if (nvec64 * 16 > slot_bytes || nvec64 > NT * kMaxIt) {
+    if (nvec64 * 16 > slot_bytes || nvec64 > NT * kQuadMaxIt) {
         // The footprint does not fit the slot planned on the host: gather this workgroup's voxels from the quad copy
         // directly.  Slow, never wrong.  (A separate function with scalar arguments: indexing the per-pixel arrays with a
         // run-time pixel index here would move them to scratch memory for the hot path too.)
@@ -466,7 +509,8 @@ __global__ __launch_bounds__(NT) void affine_march4(const float* __restrict__ sr
         case 1: run(integral_constant<int, 1>{}); break;
         case 2: run(integral_constant<int, 2>{}); break;
         case 3: run(integral_constant<int, 3>{}); break;
-        default: run(integral_constant<int, 4>{}); break;
+        case 4: run(integral_constant<int, 4>{}); break;
+        default: run(integral_constant<int, 5>{}); break;
     }
 }
 
@@ -482,6 +526,7 @@ static const QuadCfg kQuad[] = {
     {16, 64, 256},    // 3: four pixels per thread, 256-byte store rows
     {32, 32, 512},    // 4: two pixels per thread, 8 waves
 };
+int quad_max_it() { return kQuadMaxIt; }
 int quad_config_count() { return (int)(sizeof(kQuad) / sizeof(kQuad[0])); }
 void quad_config(int idx, int* th, int* tw, int* nt) { *th = kQuad[idx].th; *tw = kQuad[idx].tw; *nt = kQuad[idx].nt; }
 
@@ -541,7 +586,8 @@ hipError_t launch_affine_quad(int cfg, int interp, const float* srcq, float* out
                               int grid, int lds_bytes, hipStream_t stream)
 {
     quad_fn fn = quad_entry(cfg, interp_kind(interp));
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(kQuad[cfg].nt), lds_bytes, stream, srcq, out, p);
+    const dim3 g = (p.flags & (1 << 29)) ? dim3((unsigned)(p.nTh * p.nTw), (unsigned)p.nTd) : dim3((unsigned)grid);
+    hipLaunchKernelGGL(fn, g, dim3(kQuad[cfg].nt), lds_bytes, stream, srcq, out, p);
     return hipGetLastError();
 }
 
