@@ -55,6 +55,7 @@ enum vt_flags {
     VT_FORCE_PACKED = 256, /* diagnostic: packed footprints whenever they fit, even where boxes are cheaper          */
     VT_FORCE_XSWAP = 512,  /* diagnostic: rotations about axis 2 take the axis-exchange path for every interpolation  */
     VT_NO_RSWAP = 1024,    /* diagnostic: in-plane maps near a quarter turn sample the plain copy, not the transposed */
+    VT_ONESHOT_EDGE_SCIPY = 4096, /* vt_affine_oneshot only: build the temporary handle with VT_EDGE_SCIPY */
     VT_NO_QUAD = 2048      /* diagnostic: no plane-quad marching kernel (the plain / plane-pair marching kernels serve instead);
                               VT_NO_ZPAIR disables both interleaved layouts */
 };
@@ -64,6 +65,9 @@ enum vt_create_flags {
     VT_SRC_DEVICE = 1,       /* `data` is a device pointer on `dev` (else host memory)                    */
     VT_SLAB_LO_INTERIOR = 2, /* slab volumes: plane 0 of `data` is NOT the global volume's first plane     */
     VT_SLAB_HI_INTERIOR = 4, /* slab volumes: the last plane of `data` is NOT the global volume's last     */
+    VT_EDGE_SCIPY = 16,      /* boundary contract of the reference's CPU path (scipy.ndimage.affine_transform, mode='constant', cval=0,
+                                transforms.py:147-152) instead of the GPU path's texture contract: hard cut-off outside [0, dim-1],
+                                mirrored taps inside, mirror-boundary prefilter.  Whole-volume handles only.                 */
     VT_SRC_DEFERRED = 8      /* `data` may be NULL: the resident window starts zero-filled, is filled plane range by plane
                                 range with vt_volume_upload_planes and becomes usable with vt_volume_finalize              */
 };

@@ -367,6 +367,7 @@ void fold_matrix(const vt_volume* v, const double m4x4[16], double m[12])
         m[4 * r + 3] = std::fma(m4x4[4 * r], (double)v->out_plane0, m4x4[4 * r + 3]);
     }
     m[3] -= (double)v->plane0;
+    for (int r = 0; r < 3; ++r) m[4 * r + 3] += (double)v->edge_pad;       // VT_EDGE_SCIPY: resident coordinate = volume coordinate + pad
 }
 
 // a handle-shaped view of the same volume with axes permuted (planning only: no buffers)
@@ -378,6 +379,7 @@ vt_volume planning_view(const vt_volume* v, int D, int H, int W, int P, int oD, 
     sw.oD = oD; sw.oH = oH; sw.oW = oW;
     sw.plane0 = keep_window ? v->plane0 : 0; sw.gD = keep_window ? v->gD : D; sw.out_plane0 = keep_window ? v->out_plane0 : 0;
     sw.lds_limit = v->lds_limit; sw.cu_count = v->cu_count; sw.tune = v->tune;
+    sw.edge_pad = v->edge_pad;
     return sw;
 }
 
@@ -669,11 +671,25 @@ int create_common(int dev, int D, int H, int W, int interp, const float* data, i
     int rc = init_device(dev);
     if (rc) return rc;
 
+    const int uD = D, uH = H, uW = W;              // the caller's dims; D, H, W below are the resident copy's
+    int pad = 0;
+    if (cflags & VT_EDGE_SCIPY) {
+        if (plane0 != 0 || gD != D || out_plane0 != 0 || oD != D || (cflags & (kSrcNone | VT_SRC_DEFERRED)))
+            return fail(VT_EUNSUPPORTED, "VT_EDGE_SCIPY is available for whole-volume handles only");
+        // one mirrored voxel serves every in-range tap; the prefiltered interpolations carry 16, so that the ordinary prefilter's
+        // own boundary treatment sits 16 samples away from the data (|z|^16 = 7e-10) and what reaches the data is the
+        // mirror-boundary solution scipy computes
+        pad = is_filtered(interp) ? 16 : 1;
+        D += 2 * pad; H += 2 * pad; W += 2 * pad;
+        gD = D;
+        if ((int64_t)D * H > 0x7fffffffLL || (int64_t)H * W > 0x7fffffffLL) return fail(VT_EUNSUPPORTED, "plane count/size exceeds 2^31");
+    }
     vt_volume* v = new (std::nothrow) vt_volume();
     if (!v) return fail(VT_ENOMEM, "out of host memory");
     v->dev = dev; v->interp = interp; v->D = D; v->H = H; v->W = W;
-    v->oD = oD; v->oH = H; v->oW = W;
+    v->oD = oD; v->oH = uH; v->oW = uW;
     v->plane0 = plane0; v->gD = gD; v->out_plane0 = out_plane0;
+    v->edge_pad = pad;
     v->tune.read();
 
     auto cleanup = [&](int code) {
@@ -712,6 +728,25 @@ int create_common(int dev, int D, int H, int W, int interp, const float* data, i
         VT_HIPC(hipStreamSynchronize(v->stream));
         v->deferred = (cflags & VT_SRC_DEFERRED) != 0;
         v->lo_interior = (cflags & VT_SLAB_LO_INTERIOR) != 0;
+        *out = v;
+        return 0;
+    }
+    if (pad > 0) {
+        // dense copy of the caller's samples on the device, then one pass writes the mirrored, padded resident copy
+        const size_t ubytes = (size_t)uD * uH * uW * sizeof(float);
+        float* d_dense = nullptr;
+        VT_HIPC(cached_malloc(dev, reinterpret_cast<void**>(&d_dense), ubytes));
+        hipError_t ec;
+        {
+            PinnedScope pin((cflags & VT_SRC_DEVICE) ? nullptr : data, (cflags & VT_SRC_DEVICE) ? 0 : ubytes);
+            ec = hipMemcpyAsync(d_dense, data, ubytes, kind, v->stream);
+            if (ec == hipSuccess) ec = launch_mirror_pad(d_dense, v->d_src, uD, uH, uW, pad, v->P, v->stream);
+            if (ec == hipSuccess) ec = hipStreamSynchronize(v->stream);
+        }
+        cached_free(dev, d_dense, ubytes);
+        if (ec != hipSuccess) return cleanup(fail((int)ec, "mirror padding: %s", hipGetErrorString(ec)));
+        rc = finalize_resident(v, false);
+        if (rc) return cleanup(rc);
         *out = v;
         return 0;
     }
@@ -950,7 +985,7 @@ int do_affine_batch(vt_volume* v, int n, const double* m4x4s, float* out, int fl
         double* m = ms.data() + 12 * (size_t)i;
         for (int r = 0; r < 3; ++r) {
             for (int c = 0; c < 4; ++c) m[4 * r + c] = a[4 * r + c];
-            m[4 * r + 3] = std::fma(a[4 * r], (double)v->out_plane0, a[4 * r + 3]);
+            m[4 * r + 3] = std::fma(a[4 * r], (double)v->out_plane0, a[4 * r + 3]) + (double)v->edge_pad;
         }
         m[3] -= (double)v->plane0;
     }
@@ -1010,7 +1045,8 @@ int do_project(vt_volume* v, const double m4x4[16], float* out, int flags)
     m[3] -= (double)v->plane0;
     const bool host_out = !(flags & VT_OUT_DEVICE);
     const size_t n2 = (size_t)v->oH * v->oW;
-    const bool zsep = !(flags & VT_NO_ZSEP) && m[0] == 1.0 && m[1] == 0.0 && m[2] == 0.0 && m[4] == 0.0 && m[8] == 0.0 &&
+    // (VT_EDGE_SCIPY handles: the fused plane sum assumes the texture contract's skirt; they transform, then sum)
+    const bool zsep = v->edge_pad == 0 && !(flags & VT_NO_ZSEP) && m[0] == 1.0 && m[1] == 0.0 && m[2] == 0.0 && m[4] == 0.0 && m[8] == 0.0 &&
                       std::fabs(m[3]) < 1.0e9;
     if (zsep) {
         if (!v->proj) {
@@ -1230,7 +1266,7 @@ int vt_host_unregister(int dev, void* ptr)
 int vt_volume_create(int dev, int depth, int height, int width, int interp, const float* data,
                      int create_flags, vt_volume_t** out)
 {
-    return create_common(dev, depth, height, width, interp, data, create_flags & VT_SRC_DEVICE,
+    return create_common(dev, depth, height, width, interp, data, create_flags & (VT_SRC_DEVICE | VT_EDGE_SCIPY),
                          0, depth, 0, depth, out);
 }
 
@@ -1433,9 +1469,11 @@ int vt_affine_oneshot(int dev, const float* h_volume, int D, int H, int W, int i
     hipEventRecord(t0, nullptr);
     vt_volume_t* v = nullptr;
     static const bool no_pipe = std::getenv("VT_ONESHOT_SEQ") != nullptr;      // A/B switch: always the plain sequence
-    rc = no_pipe ? 1 : oneshot_pipelined(dev, h_volume, D, H, W, interp, m4x4, h_out, flags & ~VT_OUT_DEVICE);
+    const bool edge = (flags & VT_ONESHOT_EDGE_SCIPY) != 0;
+    flags &= ~VT_ONESHOT_EDGE_SCIPY;
+    rc = (no_pipe || edge) ? 1 : oneshot_pipelined(dev, h_volume, D, H, W, interp, m4x4, h_out, flags & ~VT_OUT_DEVICE);
     if (rc == 1) {
-        rc = vt_volume_create(dev, D, H, W, interp, h_volume, 0, &v);
+        rc = vt_volume_create(dev, D, H, W, interp, h_volume, edge ? VT_EDGE_SCIPY : 0, &v);
         if (!rc) rc = vt_volume_affine(v, m4x4, h_out, flags & ~VT_OUT_DEVICE);
     }
     hipEventRecord(t1, nullptr);

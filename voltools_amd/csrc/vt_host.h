@@ -84,6 +84,7 @@ struct vt_volume {
     float* d_proj_tmp = nullptr;       // projection of general matrices: the transformed volume before the sum
     size_t proj_tmp_elems = 0;
     vt_volume* proj = nullptr;         // projection helper: 3 x H x W volume [S, S, S] sharing this handle's stream
+    int edge_pad = 0;                  // VT_EDGE_SCIPY: the resident copy carries this many mirrored voxels on every side (0 = texture contract)
     bool owns_stream = true;
     bool deferred = false;             // created with VT_SRC_DEFERRED: planes still being uploaded, not usable before vt_volume_finalize
     bool lo_interior = false;          // ... and its VT_SLAB_LO_INTERIOR flag, kept for the prefilter at finalize

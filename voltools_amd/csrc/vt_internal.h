@@ -203,6 +203,7 @@ hipError_t launch_relayout_zpair(const float* src, float* dst, int D, int H, int
 // dst[k][j][i] = src[i][j][k]; element strides: src i*ss0 + j*ss1 + k, dst k*ds0 + j*ds1 + i (vt_kernels_layout.hip)
 hipError_t launch_transpose02(const float* src, float* dst, int n0, int n1, int n2, int64_t ss0, int64_t ss1,
                               int64_t ds0, int64_t ds1, hipStream_t stream);
+hipError_t launch_mirror_pad(const float* src, float* dst, int D, int H, int W, int R, int P, hipStream_t stream);
 hipError_t launch_relayout_swap01(const float* src, float* dst, int D, int H, int P, hipStream_t stream);
 // plane-quad marching kernel (vt_kernels_quad.hip)
 int quad_max_it();

@@ -73,4 +73,35 @@ hipError_t launch_transpose02(const float* src, float* dst, int n0, int n1, int 
     return hipGetLastError();
 }
 
+// dense [D][H][W] -> padded resident layout [(D+2R)][(H+2R)][P]: the volume with R voxels of whole-sample-symmetric ("mirror")
+// extension on every side (index -1 <- 1, n <- n-2, reflected again for extents below R), columns beyond W+2R zero.
+// scipy's spline interpolation extends its coefficients this way for taps of in-range coordinates (VT_EDGE_SCIPY).
+__device__ __forceinline__ int reflect_index(int i, int n)
+{
+    if (n == 1) return 0;
+    const int period = 2 * (n - 1);
+    i %= period;
+    if (i < 0) i += period;
+    return i < n ? i : period - i;
+}
+
+__global__ __launch_bounds__(256) void mirror_pad_kernel(const float* __restrict__ src, float* __restrict__ dst, int D, int H, int W, int R, int P)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y, z = blockIdx.z;
+    if (x >= P) return;
+    float v = 0.0f;
+    if (x < W + 2 * R)
+        v = src[((int64_t)reflect_index(z - R, D) * H + reflect_index(y - R, H)) * W + reflect_index(x - R, W)];
+    dst[((int64_t)z * (H + 2 * R) + y) * P + x] = v;
+}
+
+hipError_t launch_mirror_pad(const float* src, float* dst, int D, int H, int W, int R, int P, hipStream_t stream)
+{
+    const dim3 grid((P + 255) / 256, H + 2 * R, D + 2 * R);
+    if (grid.y > 65535 || grid.z > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mirror_pad_kernel, grid, dim3(256), 0, stream, src, dst, D, H, W, R, P);
+    return hipGetLastError();
+}
+
 }  // namespace vt

@@ -794,10 +794,21 @@ void plan_launch(const vt_volume* v, const double m[12], int flags, AffineParams
     p->ord[0] = 0; p->ord[1] = 1; p->ord[2] = 2;
     p->ia1 = march_recip(m[5]); p->ib1 = march_recip(m[6]);
     p->flags = (flags & VT_KEEP_OUTSIDE);
-    // skirt rule src + 0.5 in [0, dim) on the global volume, expressed on resident coordinates
-    p->vlo[0] = -0.5 - (double)v->plane0;  p->vhi[0] = (double)v->gD - 0.5 - (double)v->plane0;
-    p->vlo[1] = -0.5;                      p->vhi[1] = (double)v->H - 0.5;
-    p->vlo[2] = -0.5;                      p->vhi[2] = (double)v->W - 0.5;
+    if (v->edge_pad > 0) {
+        // scipy's constant mode: a coordinate outside [0, dim-1] gives 0 (transforms.py:147-152); on the padded resident copy
+        // that is [R, dim_p - R - 1], written as a half-open interval ending one ulp above the last valid coordinate
+        const double R = (double)v->edge_pad;
+        const int dims[3] = {v->D, v->H, v->W};
+        for (int r = 0; r < 3; ++r) {
+            p->vlo[r] = R;
+            p->vhi[r] = std::nextafter((double)dims[r] - R - 1.0, 1.0e300);
+        }
+    } else {
+        // skirt rule src + 0.5 in [0, dim) on the global volume, expressed on resident coordinates
+        p->vlo[0] = -0.5 - (double)v->plane0;  p->vhi[0] = (double)v->gD - 0.5 - (double)v->plane0;
+        p->vlo[1] = -0.5;                      p->vhi[1] = (double)v->H - 0.5;
+        p->vlo[2] = -0.5;                      p->vhi[2] = (double)v->W - 0.5;
+    }
     p->zero_off = ((v->W + 3) & ~3) * 4;
 
     plan->kind = 1; plan->cfg = -1; plan->td = plan->th = plan->tw = 0; plan->lds_bytes = 0; plan->grid = 0;

@@ -17,6 +17,12 @@ Differences from the reference, all deliberate (DESIGN.md "Semantics"):
     reference behaviour;
   - a device-resident *input* is never clobbered (the reference reuses it as the output buffer,
     ``transforms.py:196,208``).
+
+One extension: the keyword-only ``edge=`` argument of the GPU devices.  ``'texture'`` (default) is the reference GPU path's
+boundary contract (zero border, half-voxel skirt, ``transforms.py:187-191,276-278``); ``'scipy'`` is the contract of the
+reference's CPU path (``scipy.ndimage.affine_transform(mode='constant', cval=0)``, ``transforms.py:147-152``: hard cut-off outside
+``[0, dim-1]``, mirrored taps, mirror-boundary prefilter), so that ``device='gpu', edge='scipy'`` equals ``device='cpu'`` on the
+WHOLE volume, not just where the two contracts agree -- the equivalence ``tests/test_devices.py:43-77`` of the reference eyeballs.
 """
 import time
 from typing import Tuple, Union
@@ -45,35 +51,35 @@ def transform(volume: np.ndarray,
               rotation: Vec3 = None, rotation_units: str = 'deg', rotation_order: str = 'rzxz',
               translation: Vec3 = None, center: Vec3 = None,
               interpolation: str = 'linear', reshape: bool = False, profile: bool = False,
-              output=None, device: str = 'cpu'):
+              output=None, device: str = 'cpu', *, edge: str = 'texture'):
     """Scale, shear, rotate and translate about ``center`` (default ``(shape-1)/2``, transforms.py:38-39)."""
     if center is None:
         center = np.divide(np.subtract(volume.shape, 1), 2, dtype=np.float32)
     m = transform_matrix(_triple(scale), _triple(shear), rotation, rotation_units, rotation_order,
                          translation, center)
-    return affine(volume, m, interpolation, reshape, profile, output, device)
+    return affine(volume, m, interpolation, reshape, profile, output, device, edge=edge)
 
 
 def translate(volume: np.ndarray, translation: Vec3, interpolation: str = 'linear', reshape: bool = False,
-              profile: bool = False, output=None, device: str = 'cpu'):
-    return affine(volume, translation_matrix(translation), interpolation, reshape, profile, output, device)
+              profile: bool = False, output=None, device: str = 'cpu', *, edge: str = 'texture'):
+    return affine(volume, translation_matrix(translation), interpolation, reshape, profile, output, device, edge=edge)
 
 
 def shear(volume: np.ndarray, coefficients: Union[float, Vec3], interpolation: str = 'linear',
-          reshape: bool = False, profile: bool = False, output=None, device: str = 'cpu'):
-    return affine(volume, shear_matrix(_triple(coefficients)), interpolation, reshape, profile, output, device)
+          reshape: bool = False, profile: bool = False, output=None, device: str = 'cpu', *, edge: str = 'texture'):
+    return affine(volume, shear_matrix(_triple(coefficients)), interpolation, reshape, profile, output, device, edge=edge)
 
 
 def scale(volume: np.ndarray, coefficients: Union[float, Vec3], interpolation: str = 'linear',
-          reshape: bool = False, profile: bool = False, output=None, device: str = 'cpu'):
-    return affine(volume, scale_matrix(_triple(coefficients)), interpolation, reshape, profile, output, device)
+          reshape: bool = False, profile: bool = False, output=None, device: str = 'cpu', *, edge: str = 'texture'):
+    return affine(volume, scale_matrix(_triple(coefficients)), interpolation, reshape, profile, output, device, edge=edge)
 
 
 def rotate(volume: np.ndarray, rotation: Vec3, rotation_units: str = 'deg', rotation_order: str = 'rzxz',
            interpolation: str = 'linear', reshape: bool = False, profile: bool = False, output=None,
-           device: str = 'cpu'):
+           device: str = 'cpu', *, edge: str = 'texture'):
     m = rotation_matrix(rotation=rotation, rotation_units=rotation_units, rotation_order=rotation_order)
-    return affine(volume, m, interpolation, reshape, profile, output, device)
+    return affine(volume, m, interpolation, reshape, profile, output, device, edge=edge)
 
 
 def _scipy_arguments(interpolation: str) -> Tuple[int, bool]:
@@ -99,7 +105,7 @@ def _affine_cpu(volume, transform_m, interpolation, reshape, profile, output):
     return output if output is not None else result
 
 
-def _affine_gpu(volume, transform_m, interpolation, reshape, profile, output, dev):
+def _affine_gpu(volume, transform_m, interpolation, reshape, profile, output, dev, edge='texture'):
     if interpolation not in _INTERPOLATIONS:
         # the reference raises from _get_transform_kernel (transforms.py:234-235)
         raise ValueError(f'Interpolation must be one of {AVAILABLE_INTERPOLATIONS}')
@@ -112,7 +118,7 @@ def _affine_gpu(volume, transform_m, interpolation, reshape, profile, output, de
         from .volume import StaticVolume
         if reshape:
             raise ValueError('reshape=True needs a host (numpy) volume')
-        sv = StaticVolume(volume, interpolation=interpolation, device=f'gpu:{dev}')
+        sv = StaticVolume(volume, interpolation=interpolation, device=f'gpu:{dev}', edge=edge)
         return sv.affine(transform_m, profile=profile, output=output)
 
     volume = np.asarray(volume)
@@ -134,26 +140,32 @@ def _affine_gpu(volume, transform_m, interpolation, reshape, profile, output, de
     if is_dev:
         # device output: resident path (upload + prefilter once, then the same kernel)
         from .volume import StaticVolume
-        sv = StaticVolume(vol32, interpolation=interpolation, device=f'gpu:{dev}')
+        sv = StaticVolume(vol32, interpolation=interpolation, device=f'gpu:{dev}', edge=edge)
         return sv.affine(m32, profile=profile, output=output)
 
     import ctypes
     ms = ctypes.c_float(0.0)
     _native.check(lib.vt_affine_oneshot(dev, vol32.ctypes.data, *vol32.shape, _INTERPOLATIONS[interpolation],
-                                        m32.ctypes.data, ptr, 0, ctypes.byref(ms)), 'vt_affine_oneshot')
+                                        m32.ctypes.data, ptr, _native.ONESHOT_EDGE_SCIPY if edge == 'scipy' else 0,
+                                        ctypes.byref(ms)), 'vt_affine_oneshot')
     if profile:
         print(f'transform finished in {ms.value:.3f}ms')
     return host_out if output is None else None      # GPU branch returns None when output= is given
 
 
+EDGE_POLICIES = ('texture', 'scipy')
+
+
 def affine(volume: np.ndarray, transform_m: np.ndarray, interpolation: str = 'linear', reshape: bool = False,
-           profile: bool = False, output=None, device: str = 'cpu'):
+           profile: bool = False, output=None, device: str = 'cpu', *, edge: str = 'texture'):
     """Resample ``volume`` through the 4x4 pull matrix ``transform_m`` (transforms.py:109-229)."""
     if device not in AVAILABLE_DEVICES:
         raise ValueError(f'Unknown device ({device}), must be one of {AVAILABLE_DEVICES}')
+    if edge not in EDGE_POLICIES:
+        raise ValueError(f'edge must be one of {EDGE_POLICIES}')
     if device == 'cpu':
         return _affine_cpu(volume, transform_m, interpolation, reshape, profile, output)
     if device.startswith('gpu'):
         return _affine_gpu(volume, transform_m, interpolation, reshape, profile, output,
-                           utils.switch_to_device(device))
+                           utils.switch_to_device(device), edge)
     raise ValueError(f'No instructions for {device}.')

@@ -21,9 +21,14 @@ Vec3 = Union[Tuple[float, float, float], np.ndarray]
 class StaticVolume:
     """For StaticVolume transforms the boolean reshape cannot be given as an argument."""
 
-    def __init__(self, data, interpolation: str = 'linear', device: str = 'gpu'):
+    def __init__(self, data, interpolation: str = 'linear', device: str = 'gpu', *, edge: str = 'texture'):
+        """``edge`` (extension, GPU devices): ``'texture'`` = the reference GPU path's boundary contract, ``'scipy'`` = the
+        contract of its CPU path (see ``transforms.py`` of this package)."""
         if data.ndim != 3:
             raise ValueError('Expected a 3D array')
+        if edge not in ('texture', 'scipy'):
+            raise ValueError("edge must be 'texture' or 'scipy'")
+        self.edge = edge
         if device not in get_available_devices():
             raise ValueError(f'Unknown device ({device}), must be one of {get_available_devices()}')
 
@@ -44,6 +49,8 @@ class StaticVolume:
             else:
                 host = np.ascontiguousarray(data, dtype=np.float32)
                 ptr, flags = host.ctypes.data, 0
+            if edge == 'scipy':
+                flags |= _native.EDGE_SCIPY
             h = ctypes.c_void_p()
             _native.check(self._lib.vt_volume_create(self._dev, *self.shape, _INTERPOLATIONS[interpolation],
                                                      ptr, flags, ctypes.byref(h)), 'vt_volume_create')
