@@ -56,8 +56,10 @@ enum vt_flags {
     VT_FORCE_XSWAP = 512,  /* diagnostic: rotations about axis 2 take the axis-exchange path for every interpolation  */
     VT_NO_RSWAP = 1024,    /* diagnostic: in-plane maps near a quarter turn sample the plain copy, not the transposed */
     VT_ONESHOT_EDGE_SCIPY = 4096, /* vt_affine_oneshot only: build the temporary handle with VT_EDGE_SCIPY */
-    VT_NO_QUAD = 2048      /* diagnostic: no plane-quad marching kernel (the plain / plane-pair marching kernels serve instead);
+    VT_NO_QUAD = 2048,     /* diagnostic: no plane-quad marching kernel (the plain / plane-pair marching kernels serve instead);
                               VT_NO_ZPAIR disables both interleaved layouts */
+    VT_NO_BLOCK = 8192     /* diagnostic: general matrices use the bounding-box / packed-footprint kernels, not the lane-block
+                              kernel (VT_NO_PACKED and VT_FORCE_PACKED imply it) */
 };
 
 /* flags for vt_volume_create* */
@@ -87,7 +89,7 @@ typedef struct vt_volume_info {
     int32_t interp;
     int32_t depth, height, width;      /* resident source dims (including any slab halo planes)            */
     int32_t out_depth, out_height, out_width;
-    int32_t last_kernel;               /* 0 none, 1 direct, 2 tiled (boxes), 3 tiled axis-0-separable, 4 marching, 5 marching on plane pairs, 6 tiled (packed footprints), 7 fused projection, 8 marching on plane quads */
+    int32_t last_kernel;               /* 0 none, 1 direct, 2 tiled (boxes), 3 tiled axis-0-separable, 4 marching, 5 marching on plane pairs, 6 tiled (packed footprints), 7 fused projection, 8 marching on plane quads, 9 lane-block tiles (general matrices) */
     int32_t last_tile[3];              /* output tile (TD, TH, TW) of the last tiled launch (marching: G, TH, TW) */
     int32_t last_lds_dims[3];          /* staged source box (Lz, Ly, Lx) (marching: ring slots, Ly, Lx)    */
     int32_t last_lds_bytes;

@@ -100,7 +100,7 @@ def test_config4_general_rotation_1024_sub_block(big):
     m = vt.utils.transform_matrix(rotation=(25, -40, 70), rotation_order='sxyz', center=centre((N, N, N)))
     sv.affine(m, output=out)
     k = sv.info().last_kernel
-    assert k in (2, 6, 8), k
+    assert k in (2, 6, 8, 9), k
     sv.affine(m, output=out2, _flags=_native.FORCE_DIRECT)
     sv.synchronize()
     assert float((t_out - t_out2).abs().max().item()) <= 2e-6

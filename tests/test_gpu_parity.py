@@ -78,6 +78,7 @@ def test_tiled_and_direct_match_oracle(interp, mname, shape):
     for flags in (_native.FORCE_TILED | _native.FORCE_XSWAP, _native.FORCE_TILED | _native.FORCE_XSWAP | _native.NO_ZPAIR,
                   _native.FORCE_TILED | _native.FORCE_XSWAP | _native.NO_QUAD, _native.FORCE_TILED | _native.NO_QUAD | _native.NO_RSWAP,
                   _native.FORCE_TILED, _native.FORCE_TILED | _native.NO_RSWAP, _native.FORCE_TILED | _native.NO_MARCH,
+                  _native.FORCE_TILED | _native.NO_ZSEP, _native.FORCE_TILED | _native.NO_ZSEP | _native.NO_BLOCK,
                   _native.FORCE_TILED | _native.NO_ZSEP | _native.FORCE_PACKED, _native.FORCE_TILED | _native.NO_ZSEP | _native.NO_PACKED,
                   _native.FORCE_DIRECT):
         got, info = run_case(vol, m, interp, flags)
@@ -94,6 +95,8 @@ def test_tiled_and_direct_match_oracle(interp, mname, shape):
         assert 2 in kernels and 1 in kernels
     if mname in ('rot_general', 'shear', 'rot_scale_shift', 'minify', 'mirror'):
         assert 6 in kernels                          # packed-footprint kernel for invertible general matrices
+    if mname in ('rot_general', 'shear', 'rot_scale_shift', 'mirror', 'rot_axis1', 'rot_axis2_shift', 'rot_inplane45', 'shift_frac'):
+        assert 9 in kernels                          # lane-block kernel: every matrix whose tile footprint fits its LDS rows
 
 
 @pytest.mark.parametrize('interp', ['linear', 'bspline', 'filt_bspline_simple'])
@@ -144,6 +147,9 @@ def test_default_dispatch_uses_tiled_kernel_on_large_volumes(interp):
     vol = rand_vol(shape, 2)
     m = MATRICES['rot_general'](shape)
     got, info = run_case(vol, m, interp)
+    assert info.last_kernel == 9 and info.last_lds_bytes > 0          # general matrices: the lane-block kernel
+    assert np.abs(got - oracle.affine(vol, m, interp)).max() <= TOL[interp]
+    got, info = run_case(vol, m, interp, _native.NO_BLOCK)
     # a volume this small has too few tiles to amortise the packed kernel's per-workgroup set-up: bounding boxes
     assert info.last_kernel == 2 and info.last_lds_bytes > 0
     assert np.abs(got - oracle.affine(vol, m, interp)).max() <= TOL[interp]
@@ -549,10 +555,13 @@ def test_full_size_properties_512(interp):
     m = vt.utils.transform_matrix(rotation=(25, -40, 70), rotation_order='sxyz', center=centre((n, n, n)))
     sv.affine(m, output=out)
     a = out.get()
-    assert sv.info().last_kernel == (6 if interp == 'linear' else 2)      # packed footprints are planned for trilinear only
+    assert sv.info().last_kernel == 9
     sv.affine(m, output=out, _flags=_native.FORCE_DIRECT)
     b = out.get()
     assert np.abs(a - b).max() <= tol
+    sv.affine(m, output=out, _flags=_native.NO_BLOCK)
+    assert sv.info().last_kernel == (6 if interp == 'linear' else 2)      # packed footprints are planned for trilinear only
+    assert np.abs(out.get() - b).max() <= tol
     sv.affine(m, output=out, _flags=_native.NO_PACKED)
     assert sv.info().last_kernel == 2
     assert np.abs(out.get() - b).max() <= tol
@@ -563,6 +572,9 @@ def test_full_size_properties_512(interp):
         a = out.get()
         assert sv.info().last_kernel == 8 or (rot[2] and interp == 'linear'), rot
         sv.affine(m, output=out, _flags=_native.NO_ZSEP)
+        assert sv.info().last_kernel == 9
+        assert np.abs(a - out.get()).max() <= tol, rot
+        sv.affine(m, output=out, _flags=_native.NO_ZSEP | _native.NO_BLOCK)
         assert sv.info().last_kernel in (2, 6)
         assert np.abs(a - out.get()).max() <= tol, rot
         sv.affine(m, output=out, _flags=_native.FORCE_DIRECT)
@@ -582,6 +594,9 @@ def test_full_size_properties_512(interp):
     assert sv.info().last_kernel == 3
     assert np.abs(a - out.get()).max() <= tol
     sv.affine(m, output=out, _flags=_native.NO_ZSEP)
+    assert sv.info().last_kernel == 9
+    assert np.abs(a - out.get()).max() <= tol
+    sv.affine(m, output=out, _flags=_native.NO_ZSEP | _native.NO_BLOCK)
     assert sv.info().last_kernel == 2
     assert np.abs(a - out.get()).max() <= tol
     sv.affine(m, output=out, _flags=_native.NO_ZSEP | _native.FORCE_PACKED)

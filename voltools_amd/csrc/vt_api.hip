@@ -264,6 +264,7 @@ int init_device(int dev)
         std::call_once(g_init_flag[dev], [dev]() {
             g_init_err[dev] = init_affine_kernels();
             if (g_init_err[dev] == hipSuccess) g_init_err[dev] = init_quad_kernels();
+            if (g_init_err[dev] == hipSuccess) g_init_err[dev] = init_block_kernels();
             hipDeviceProp_t prop;
             if (g_init_err[dev] == hipSuccess) g_init_err[dev] = hipGetDeviceProperties(&prop, dev);
             if (g_init_err[dev] == hipSuccess) {
@@ -549,6 +550,8 @@ int launch_planned(vt_volume* v, const TilePlan& plan, const AffineParams& p, co
             VT_HIP(launch_relayout_zpair(ori.src_plain, *ori.pair_slot, ori.srcD, ori.srcH, ori.pair_W, ori.pair_P, v->P2, v->stream));
         }
         VT_HIP(launch_affine_zpair(plan.cfg, v->interp, *ori.pair_slot, d_out, p, plan.grid, plan.lds_bytes, v->stream));
+    } else if (plan.kind == 9) {
+        VT_HIP(launch_affine_block(plan.cfg, v->interp, plan.lm, v->d_src, d_out, v->d_zeros, p, plan.grid, plan.lds_bytes, v->stream));
     } else if (plan.kind == 6) {
         VT_HIP(launch_affine_packed(plan.cfg, v->interp, v->d_src, d_out, v->d_zeros, p, plan.geo, plan.grid, plan.lds_bytes, v->stream));
     } else if (plan.kind == 4) {

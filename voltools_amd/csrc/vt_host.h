@@ -24,6 +24,10 @@ struct Tuning {
     int quad_rows = -2;            // VT_QUAD_ROWS: -1 = rows packed back to back, 0..15 = force the row stride S of the bank-aware placement, -2 = planner
     int quad_grid2d = 1;           // VT_QUAD_GRID2D=0: 1-D grid with XCD-contiguous ids over all chunks (round-2 A/B)
     int quad_nt = -1;              // VT_QUAD_NT: 1 / 0 = nontemporal / plain output stores of the plane-quad kernel, -1 = planner's choice
+    bool no_block = false;         // VT_NO_BLOCK_KERNEL: general matrices on the round-1 box / packed kernels
+    int block_rs = -1;             // VT_BLOCK_RS: force the row-stride index of the lane-block kernel (if it holds the box)
+    int block_lm = -1;             // VT_BLOCK_LM: lane map of the lane-block kernel (0 = 4x4x4 blocks, 1 = rows of 16)
+    int block_pad = -1;            // VT_BLOCK_PAD: plane-stride padding in floats instead of the bank model's choice
     void read()
     {
         auto num = [](const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; };
@@ -44,6 +48,11 @@ struct Tuning {
         quad_nt = num("VT_QUAD_NT", -1);
         quad_grid2d = num("VT_QUAD_GRID2D", 1);
         quad_rows = num("VT_QUAD_ROWS", -2);
+        no_block = std::getenv("VT_NO_BLOCK_KERNEL") != nullptr;
+        block_rs = num("VT_BLOCK_RS", -1);
+        block_lm = num("VT_BLOCK_LM", -1);
+        if (block_lm > 1) block_lm = 1;
+        block_pad = num("VT_BLOCK_PAD", -1);
     }
 };
 

@@ -48,6 +48,9 @@ struct AffineParams {
     int32_t row_s;             // plane-quad kernel: bank-aware row starts, slot = column + row * row_s (mod 16); -1 = rows packed back to back
     int32_t dshift;            // plane-quad kernel: chunk c > 0 starts at output plane c*dch + dshift (0..3), chosen so that a chunk's first
                                // tap plane is the first plane of a quad (one quad step per chunk beyond its own planes instead of two)
+    int32_t Lps;               // block kernel: LDS plane stride in floats (Ly * row stride + bank padding, multiple of 4)
+    int32_t binc_hi[3][3];     // block kernel: Q32.32 increments of the three steps between a thread's four voxels, [step][source axis]
+    uint32_t binc_lo[3][3];
 };
 
 
@@ -119,7 +122,8 @@ struct PackGeom {
 
 struct TilePlan {
     int kind;            // 1 direct, 2 tiled, 3 tiled axis-0-separable, 4 marching, 5 marching on plane pairs, 6 tiled with packed footprints,
-                         // 8 marching on plane quads
+                         // 8 marching on plane quads, 9 lane-block tiles (cfg = row-stride index, lm = lane map)
+    int lm;
     int cfg;             // index into the tile table
     int td, th, tw;
     int lds_bytes;
@@ -214,6 +218,15 @@ hipError_t init_quad_kernels();
 hipError_t launch_relayout_zquad(const float* src, float* dst, int D, int H, int W, int P, int Pq, hipStream_t stream);
 hipError_t launch_affine_quad(int cfg, int interp, const float* srcq, float* out, const AffineParams& p,
                               int grid, int lds_bytes, hipStream_t stream);
+// lane-block kernel for general matrices (vt_kernels_block.hip)
+int block_rs_count();
+int block_rs(int idx);
+int block_max_vectors();
+void block_tile(int* td, int* th, int* tw);
+int block_blocks_per_cu(int rs_idx, int interp, int lm, int lds_bytes);
+hipError_t init_block_kernels();
+hipError_t launch_affine_block(int rs_idx, int interp, int lm, const float* src, float* out, const float* zeros16,
+                               const AffineParams& p, int grid, int lds_bytes, hipStream_t stream);
 int packed_config_count();
 void packed_config(int idx, int* td, int* th, int* tw);
 int packed_rows_max();

@@ -1,0 +1,357 @@
+// vt_kernels_block.hip -- general matrices (true 3-D rotations, the reference's own benchmark protocol, tests/benchmark.py:52-54):
+// 8 x 8 x 16 output tiles gathered from a bank-tuned LDS box by compact lane blocks (kernel id 9, gfx950).
+//
+// What bounded the bounding-box kernel (`affine_tiled`, vt_kernels_affine.hip) on 512^3 cubic rotations was neither HBM nor LDS
+// bytes but instruction issue: 327 wave-instructions per 64 voxels (234 VALU, 38-48 LDS, 40 SALU), SQ_ACTIVE_INST_ANY = 90 % of
+// the run time (profiles/r02_general512_cubic_summary.json), plus a gather conflict degree of 2.1 on the LDS side.  This kernel is
+// the same algorithm with the instruction stream and the LDS image designed together:
+//   * the LDS row stride RS is a template constant: the 16 tap rows x 3 eight-byte reads of a cubic voxel are immediates off
+//     8 address registers (4 planes x {first two pairs, third pair}) instead of 32 computed addresses;
+//   * the 64 taps are summed as 48 packed FMAs (v_pk_fma_f32) on the pairs as they come back from `ds_read_b64`:
+//     S_k += (wz_c * wy_b) * pair_k(c, b), k = 0..2, then the six parity-shifted x weights once per voxel;
+//   * a 32-lane group of `ds_read_b64` is a 2 x 4 x 4 block of output voxels, not 2 rows of 16: its taps sit in a compact source
+//     neighbourhood, and the plane stride (a run-time value: Ly * RS + pad) is chosen per matrix by the host's bank model so that
+//     this neighbourhood spreads over the 32 bank pairs (tools/gather_b64_sim.py: conflict degree 1.6 instead of 2.2);
+//   * workgroups are persistent and keep the box-relative source offset of each of their staging vectors in registers: staging a
+//     tile is one `buffer_load ... lds` per 16-byte vector and nothing else (box wholly inside the volume; the checked path
+//     serves tiles at the border);
+//   * coordinates step in Q32.32 between the four voxels of a thread (Gray order: one increment per step), output offsets are a
+//     per-thread register plus a per-step scalar.
+// The arithmetic differs from `affine_tiled` only in the association of the 64-term sum (pairs, then x), i.e. by float32
+// rounding of a convex combination; tests hold it to the same tolerance against the oracle.
+#include "vt_internal.h"
+#include "vt_device.h"
+
+#include <algorithm>
+
+namespace vt {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+constexpr int kBlkTD = 8, kBlkTH = 8, kBlkTW = 16;
+constexpr int kBlkMaxIt = 16;                 // staging vectors per thread: boxes up to 4096 vectors = 64 KiB
+
+template <int OFF>
+__device__ __forceinline__ void lds_read_b64(v2f& r, unsigned a)
+{
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(a), "n"(OFF));
+}
+
+__device__ __forceinline__ v2f pk_fma(v2f a, float w, v2f c) { return __builtin_elementwise_fma(a, (v2f)(w), c); }
+
+// 64 taps of one voxel.  a0 = LDS byte address of column e (even) of tap row (z tap 0, y tap 0); ps4 = plane stride in bytes.
+template <bool SIMPLE, int RS>
+__device__ __forceinline__ float cubic_block_sample(unsigned a0, unsigned ps4, int par, float fz, float fy, float fx)
+{
+    constexpr int RS4 = RS * 4;
+    float wx[4], wy[4], wz[4];
+    cubic_weights<SIMPLE>(fx, wx);
+    cubic_weights<SIMPLE>(fy, wy);
+    cubic_weights<SIMPLE>(fz, wz);
+    // taps e+par .. e+par+3 of the six values (e .. e+5): weights shifted by the parity; par = 0 re-reads the second pair as
+    // the third (weight 0), so nothing beyond the row's taps is touched
+    const v2f W0 = {par ? 0.f : wx[0], par ? wx[0] : wx[1]};
+    const v2f W1 = {par ? wx[1] : wx[2], par ? wx[2] : wx[3]};
+    const v2f W2 = {par ? wx[3] : 0.f, 0.f};
+    const unsigned off3 = par ? 16u : 8u;
+    unsigned a[4], b[4];
+    a[0] = a0; a[1] = a0 + ps4; a[2] = a[1] + ps4; a[3] = a[2] + ps4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) b[c] = a[c] + off3;
+
+    // eight batches of two tap rows (6 reads); two batches in flight
+    v2f t[2][6];
+#define VT_BLK_ISSUE(c, h, r)                                                                                                   \
+    lds_read_b64<(2 * h) * RS4>(r[0], a[c]); lds_read_b64<(2 * h) * RS4 + 8>(r[1], a[c]); lds_read_b64<(2 * h) * RS4>(r[2], b[c]);     \
+    lds_read_b64<(2 * h + 1) * RS4>(r[3], a[c]); lds_read_b64<(2 * h + 1) * RS4 + 8>(r[4], a[c]); lds_read_b64<(2 * h + 1) * RS4>(r[5], b[c]);
+#define VT_BLK_WAIT(n, r) \
+    asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]));
+#define VT_BLK_SUM(c, h, r)                                                                       \
+    {                                                                                             \
+        const float w0 = wz[c] * wy[2 * h], w1 = wz[c] * wy[2 * h + 1];                           \
+        S0 = pk_fma(r[0], w0, S0); S1 = pk_fma(r[1], w0, S1); S2 = pk_fma(r[2], w0, S2);          \
+        S0 = pk_fma(r[3], w1, S0); S1 = pk_fma(r[4], w1, S1); S2 = pk_fma(r[5], w1, S2);          \
+    }
+    v2f S0 = {0.f, 0.f}, S1 = {0.f, 0.f}, S2 = {0.f, 0.f};
+    VT_BLK_ISSUE(0, 0, t[0])
+    VT_BLK_ISSUE(0, 1, t[1]) VT_BLK_WAIT(6, t[0]) VT_BLK_SUM(0, 0, t[0])
+    VT_BLK_ISSUE(1, 0, t[0]) VT_BLK_WAIT(6, t[1]) VT_BLK_SUM(0, 1, t[1])
+    VT_BLK_ISSUE(1, 1, t[1]) VT_BLK_WAIT(6, t[0]) VT_BLK_SUM(1, 0, t[0])
+    VT_BLK_ISSUE(2, 0, t[0]) VT_BLK_WAIT(6, t[1]) VT_BLK_SUM(1, 1, t[1])
+    VT_BLK_ISSUE(2, 1, t[1]) VT_BLK_WAIT(6, t[0]) VT_BLK_SUM(2, 0, t[0])
+    VT_BLK_ISSUE(3, 0, t[0]) VT_BLK_WAIT(6, t[1]) VT_BLK_SUM(2, 1, t[1])
+    VT_BLK_ISSUE(3, 1, t[1]) VT_BLK_WAIT(6, t[0]) VT_BLK_SUM(3, 0, t[0])
+    VT_BLK_WAIT(0, t[1]) VT_BLK_SUM(3, 1, t[1])
+#undef VT_BLK_ISSUE
+#undef VT_BLK_WAIT
+#undef VT_BLK_SUM
+    const v2f acc = __builtin_elementwise_fma(W0, S0, __builtin_elementwise_fma(W1, S1, W2 * S2));
+    return acc.x + acc.y;
+}
+
+// Stage the box with per-vector bounds tests (tiles whose box leaves the volume): vectors outside come from a block of zeros.
+template <int RS>
+__device__ __forceinline__ void stage_block_checked(float* lds, const float* __restrict__ src, const float* __restrict__ zeros16,
+                                                    const AffineParams& p, const int (&o)[3], int total, int psv, int nvx_used, int tid)
+{
+    constexpr int nvx = RS / 4;
+    const int wave_first = __builtin_amdgcn_readfirstlane(tid & ~63);
+    for (int vb = wave_first; vb < total; vb += 256) {
+        const int v = vb + (tid & 63);
+        const int z = v / psv, rem = v - z * psv;
+        const int y = rem / nvx, cx = rem - y * nvx;
+        const int gz = o[0] + z, gy = o[1] + y, gx = o[2] + 4 * cx;
+        const bool inb = (y < p.Ly) && (cx < nvx_used) && (unsigned)gz < (unsigned)p.sD && (unsigned)gy < (unsigned)p.sH &&
+                         (unsigned)gx < (unsigned)p.sP;
+        const float* g = inb ? src + (((int64_t)gz * p.sH + gy) * p.sP + gx) : zeros16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(lds + 4 * vb), 16, 0, 0);
+    }
+}
+
+// LM: lane -> voxel map.  0: a wave is a 4 x 4 x 4 block (32-lane groups 2 x 4 x 4), the workgroup 4 x 8 x 8, steps w+8, d+4, w-8.
+//                         1: a wave is 4 rows of 16 (32-lane groups 2 x 16), the workgroup 4 x 4 x 16, steps h+4, d+4, h-4.
+template <int KIND, int RS, int LM>
+__global__ __launch_bounds__(256, KIND == 0 ? 5 : 3) void affine_block(const float* __restrict__ src, float* __restrict__ out,
+                                                     const float* __restrict__ zeros16, const AffineParams p)
+{
+    constexpr bool CUBIC = KIND != 0;
+    constexpr int HALO = CUBIC ? 1 : 0;
+    constexpr int TD = kBlkTD, TH = kBlkTH, TW = kBlkTW;
+    constexpr int nvx = RS / 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wave_first = __builtin_amdgcn_readfirstlane(tid & ~63);
+    int vd, vh, vw;
+    if constexpr (LM == 0) { vd = lane >> 4; vh = 4 * (wv >> 1) + ((lane >> 2) & 3); vw = 4 * (wv & 1) + (lane & 3); }
+    else { vd = wv; vh = lane >> 4; vw = lane & 15; }
+    constexpr int sd[4] = {0, 0, 4, 4};
+    constexpr int sh[4] = {0, LM == 0 ? 0 : 4, LM == 0 ? 0 : 4, 0};
+    constexpr int sw[4] = {0, LM == 0 ? 8 : 0, LM == 0 ? 8 : 0, 0};
+
+    const int Lz = p.Lz, Ly = p.Ly, ps = p.Lps;
+    const int psv = ps >> 2;
+    const int total = Lz * psv;                                  // staging vectors (<= 256 * kBlkMaxIt, host-checked)
+    const int nvx_used = p.Lx_used >> 2;
+    const int row_b = p.sP * 4;
+    const int plane_b = p.sH * row_b;                            // Lz * plane_b < 2^31 (host-checked)
+
+    // box-relative byte offset of this thread's staging vectors; slots that hold no data (row / plane padding) re-read vector 0
+    int voff[kBlkMaxIt];
+#pragma unroll
+    for (int k = 0; k < kBlkMaxIt; ++k) {
+        const int v = k * 256 + tid;
+        const int z = v / psv, rem = v - z * psv;
+        const int y = rem / nvx, cx = rem - y * nvx;
+        voff[k] = (v < total && y < Ly && cx < nvx_used) ? z * plane_b + y * row_b + 16 * cx : 0;
+    }
+
+    const bool keep = (p.flags & VT_KEEP_OUTSIDE) != 0;
+    const int64_t ostride = (int64_t)p.oH * p.oW;
+    const int obase = (int)((vd * ostride + (int64_t)vh * p.oW + vw) * 4);     // TD * ostride * 4 < 2^31 (host-checked)
+    int ostep[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) ostep[s] = (int)((sd[s] * ostride + (int64_t)sh[s] * p.oW + sw[s]) * 4);
+    const unsigned ps4 = 4u * (unsigned)ps;
+    const unsigned lds_base = lds_byte_address(lds);
+#ifdef VT_EXPERIMENTS      // make EXTRA=-DVT_EXPERIMENTS: VT_EXP_NOSTORE / VT_EXP_NOLOAD / VT_EXP_NOLDS ablations
+    const bool no_stores = (p.flags & (1 << 21)) != 0, no_loads = (p.flags & (1 << 22)) != 0, no_lds = (p.flags & (1 << 26)) != 0;
+#else
+    constexpr bool no_stores = false, no_loads = false, no_lds = false;
+#endif
+
+    // A workgroup serves a brick of 2 x 2 x 2 tiles (the staging offsets above are computed once for eight tiles); bricks are
+    // dispatched by the hardware in id order, so the workgroups in flight on one XCD (blockIdx % 8) always form a compact window
+    // of consecutive bricks whose overlapping boxes meet in that XCD's L2 -- with statically strided persistent workgroups the
+    // window frays as soon as some workgroups meet cheap tiles (outside the volume), and the L2 hit rate of the staging loads
+    // fell to 0.62 (8 bytes fetched beyond L2 per algorithmic byte).  Brick ids: 4 x 4 x 4 tiles per super-block, w fastest.
+    const int nbricks = blocked_tile_count(p.nTd, p.nTh, p.nTw) >> 3;
+    const int brick = xcd_contiguous(blockIdx.x, nbricks);
+    const int nSh = (p.nTh + 3) >> 2, nSw = (p.nTw + 3) >> 2;
+    const int sb = brick >> 3, bq = brick & 7;
+    const int sbw = sb % nSw, sb2 = sb / nSw;
+    const int sbh = sb2 % nSh, sbd = sb2 / nSh;
+    for (int t = 0; t < 8; ++t) {
+        const int td_i = sbd * 4 + 2 * (bq >> 2) + (t >> 2);
+        const int th_i = sbh * 4 + 2 * ((bq >> 1) & 1) + ((t >> 1) & 1);
+        const int tw_i = sbw * 4 + 2 * (bq & 1) + (t & 1);
+        if (td_i >= p.nTd || th_i >= p.nTh || tw_i >= p.nTw) continue;
+        const int d0 = td_i * TD, h0 = th_i * TH, w0 = tw_i * TW;
+
+        // ---- tile geometry (wave-uniform, float64) ----
+        double base[3], lo[3], hi[3];
+        bool any_valid = true, all_valid = true;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            base[r] = fma(p.m[4 * r], (double)d0, fma(p.m[4 * r + 1], (double)h0, fma(p.m[4 * r + 2], (double)w0, p.m[4 * r + 3])));
+            lo[r] = base[r] + p.neg[r];
+            hi[r] = base[r] + p.pos[r];
+            any_valid = any_valid && (hi[r] >= p.vlo[r] - kTileMargin) && (lo[r] < p.vhi[r] + kTileMargin);
+            all_valid = all_valid && (lo[r] >= p.vlo[r] + kTileMargin) && (hi[r] < p.vhi[r] - kTileMargin);
+        }
+        float* const otile = out + ((int64_t)d0 * ostride + (int64_t)h0 * p.oW + w0);
+        __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(otile), 0, 0x7fffffff, 0x00020000);
+        const bool whole = (d0 + TD <= p.oD) && (h0 + TH <= p.oH) && (w0 + TW <= p.oW);
+
+        if (!any_valid) {
+            // the whole tile maps outside the valid interval: zero-fill (or leave untouched)
+            if (!keep) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int d = d0 + vd + sd[s], h = h0 + vh + sh[s], w = w0 + vw + sw[s];
+                    if (whole || (d < p.oD && h < p.oH && w < p.oW))
+                        __builtin_amdgcn_raw_buffer_store_b32(0u, orsrc, obase, ostep[s], 0);
+                }
+            }
+            continue;
+        }
+
+        int o[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) o[r] = (int)floor(lo[r]) - HALO;
+        o[2] &= ~3;
+        const bool box_inside = o[0] >= 0 && o[1] >= 0 && o[2] >= 0 && o[0] + Lz <= p.sD && o[1] + Ly <= p.sH && o[2] + p.Lx_used <= p.sP;
+
+        __syncthreads();                                         // everyone is done gathering from the previous box
+        if (no_loads) {
+        } else if (box_inside) {
+            __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char*>(reinterpret_cast<const char*>(src + (((int64_t)o[0] * p.sH + o[1]) * p.sP + o[2]))), 0, 0x7fffffff, 0x00020000);
+            char* dst = reinterpret_cast<char*>(lds) + 16 * wave_first;
+#pragma unroll
+            for (int k = 0; k < kBlkMaxIt; ++k)
+                if (k * 256 + wave_first < total)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + 4096 * k), 16, voff[k], 0, 0, 0);
+        } else {
+            stage_block_checked<RS>(lds, src, zeros16, p, o, total, psv, nvx_used, tid);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        // ---- gather ----
+        Fx c[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            c[r] = to_fx(fma(p.m[4 * r], (double)vd, fma(p.m[4 * r + 1], (double)vh, fma(p.m[4 * r + 2], (double)vw, base[r] - (double)o[r]))));
+        const bool fast = all_valid && whole;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float val;
+            if (no_lds) {
+                val = fx_frac(c[0]) + fx_frac(c[1]) + fx_frac(c[2]);
+            } else if constexpr (CUBIC) {
+                const int x1 = c[2].hi - 1, par = x1 & 1, e = x1 - par;
+                const unsigned a0 = lds_base + 4u * (unsigned)(__mul24(c[0].hi - 1, ps) + __mul24(c[1].hi - 1, RS) + e);
+                val = cubic_block_sample<KIND == 2, RS>(a0, ps4, par, fx_frac(c[0]), fx_frac(c[1]), fx_frac(c[2]));
+            } else {
+                const float* q = lds + (__mul24(c[0].hi, ps) + __mul24(c[1].hi, RS) + c[2].hi);
+                const float* q1 = q + ps;
+                const float fz = fx_frac(c[0]), fy = fx_frac(c[1]), fx = fx_frac(c[2]);
+                const float a000 = q[0], a001 = q[1], a010 = q[RS], a011 = q[RS + 1];
+                const float a100 = q1[0], a101 = q1[1], a110 = q1[RS], a111 = q1[RS + 1];
+                const float x00 = fmaf(fx, a001 - a000, a000);
+                const float x01 = fmaf(fx, a011 - a010, a010);
+                const float x10 = fmaf(fx, a101 - a100, a100);
+                const float x11 = fmaf(fx, a111 - a110, a110);
+                const float y0 = fmaf(fy, x01 - x00, x00);
+                const float y1 = fmaf(fy, x11 - x10, x10);
+                val = fmaf(fz, y1 - y0, y0);
+            }
+            if (no_stores) {
+                if (val == 123.456f) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), orsrc, obase, ostep[s], 0);
+            } else if (fast) {
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), orsrc, obase, ostep[s], 0);
+            } else {
+                // tiles cut by the skirt or by the end of the output: the inside test is the canonical float64 chain
+                const int d = d0 + vd + sd[s], h = h0 + vh + sh[s], w = w0 + vw + sw[s];
+                if (d < p.oD && h < p.oH && w < p.oW) {
+                    const bool inside = canonical_inside(p, d, h, w);
+                    if (inside) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), orsrc, obase, ostep[s], 0);
+                    else if (!keep) __builtin_amdgcn_raw_buffer_store_b32(0u, orsrc, obase, ostep[s], 0);
+                }
+            }
+            if (s < 3) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) fx_step(c[r], p.binc_hi[s][r], p.binc_lo[s][r]);
+            }
+            __builtin_amdgcn_sched_barrier(0);                   // one voxel's weights and taps in registers at a time
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+typedef void (*block_fn)(const float*, float*, const float*, const AffineParams);
+
+static const int kBlkRS[] = {20, 28, 36};
+int block_rs_count() { return (int)(sizeof(kBlkRS) / sizeof(kBlkRS[0])); }
+int block_rs(int idx) { return kBlkRS[idx]; }
+int block_max_vectors() { return 256 * kBlkMaxIt; }
+void block_tile(int* td, int* th, int* tw) { *td = kBlkTD; *th = kBlkTH; *tw = kBlkTW; }
+
+template <int RS, int LM>
+static block_fn pick_block_kind(int kind)
+{
+    switch (kind) {
+        case 0: return affine_block<0, RS, LM>;
+        case 1: return affine_block<1, RS, LM>;
+        default: return affine_block<2, RS, LM>;
+    }
+}
+
+static block_fn block_entry(int rs_idx, int kind, int lm)
+{
+    if (lm == 0) {
+        switch (rs_idx) {
+            case 0: return pick_block_kind<20, 0>(kind);
+            case 1: return pick_block_kind<28, 0>(kind);
+            default: return pick_block_kind<36, 0>(kind);
+        }
+    }
+    switch (rs_idx) {
+        case 0: return pick_block_kind<20, 1>(kind);
+        case 1: return pick_block_kind<28, 1>(kind);
+        default: return pick_block_kind<36, 1>(kind);
+    }
+}
+
+hipError_t init_block_kernels()
+{
+    for (int rs = 0; rs < block_rs_count(); ++rs)
+        for (int kind = 0; kind < 3; ++kind)
+            for (int lm = 0; lm < 2; ++lm) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(block_entry(rs, kind, lm)),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return e;
+            }
+    return hipSuccess;
+}
+
+// resident workgroups per CU (registers and LDS), cached per (kernel, LDS bytes rounded up to 4 KiB)
+int block_blocks_per_cu(int rs_idx, int interp, int lm, int lds_bytes)
+{
+    static int cache[3][3][2][41] = {};
+    const int kind = interp_kind(interp);
+    const int slot = std::min(40, (lds_bytes + 4095) / 4096);
+    int& c = cache[rs_idx][kind][lm][slot];
+    if (c == 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(block_entry(rs_idx, kind, lm)), 256, (size_t)slot * 4096) != hipSuccess || n < 1) {
+            (void)hipGetLastError();
+            n = 1;
+        }
+        c = n;
+    }
+    return c;
+}
+
+hipError_t launch_affine_block(int rs_idx, int interp, int lm, const float* src, float* out, const float* zeros16,
+                               const AffineParams& p, int grid, int lds_bytes, hipStream_t stream)
+{
+    hipLaunchKernelGGL(block_entry(rs_idx, interp_kind(interp), lm), dim3(grid), dim3(256), lds_bytes, stream, src, out, zeros16, p);
+    return hipGetLastError();
+}
+
+}  // namespace vt

@@ -13,6 +13,7 @@
 //   packed     6   affine_tiled_packed (vt_kernels_packed.hip)     invertible general matrices, trilinear (or forced)
 //   direct     1   affine_direct       (vt_kernels_affine.hip)     everything else (tiny volumes, huge footprints)
 #include "vt_host.h"
+#include "vt_device.h"
 
 #include <cmath>
 #include <cstring>
@@ -754,6 +755,109 @@ bool plan_packed(PlanCtx& c, bool have_box, double box_bpv)
     return true;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// block: 8 x 8 x 16 tiles, bank-tuned LDS box, compact lane blocks, persistent workgroups (kind 9)
+// ---------------------------------------------------------------------------------------------------
+// LDS cycles of one `ds_read_b64` of the cubic gather (1.0 = conflict-free) for a 32-lane group of the lane map: the worst
+// bank pair's count of distinct 8-byte words.  The 48 reads of a voxel are the same 32 addresses shifted by constants, so one
+// read per tile position is the whole gather.  Linear interpolation reads 4-byte words from 32 banks.
+double block_conflicts(const double m[12], int lm, int RS, int PS, bool cubic)
+{
+    static const double kBase[4][3] = {{8.13, 8.27, 8.41}, {8.44, 8.50, 8.78}, {8.71, 8.09, 8.33}, {8.92, 8.66, 8.05}};
+    double tot = 0;
+    for (int b = 0; b < 4; ++b) {
+        int words[32], n = 0;
+        for (int l = 0; l < 32; ++l) {
+            const int t[3] = {lm == 0 ? (l >> 4) : 0, lm == 0 ? ((l >> 2) & 3) : (l >> 4), lm == 0 ? (l & 3) : (l & 15)};
+            int f[3];
+            for (int r = 0; r < 3; ++r)
+                f[r] = (int)std::floor(kBase[b][r] + 24.0 + m[4 * r] * t[0] + m[4 * r + 1] * t[1] + m[4 * r + 2] * t[2]);
+            const int a = f[0] * PS + f[1] * RS + (cubic ? (((f[2] - 1) & ~1) >> 1) * 2 : f[2]);
+            const int word = cubic ? (a >> 1) : a;
+            bool seen = false;
+            for (int i = 0; i < n; ++i) seen = seen || words[i] == word;
+            if (!seen) words[n++] = word;
+        }
+        int cnt[32] = {0}, worst = 0;
+        for (int i = 0; i < n; ++i) worst = std::max(worst, ++cnt[((words[i] % 32) + 32) % 32]);
+        tot += worst;
+    }
+    return tot / 4.0;
+}
+
+bool plan_block(PlanCtx& c)
+{
+    const vt_volume* v = c.v;
+    const double* m = c.m;
+    AffineParams* p = c.p;
+    TilePlan* plan = c.plan;
+    if ((c.flags & (VT_NO_BLOCK | VT_NO_PACKED | VT_FORCE_PACKED)) || v->tune.no_block) return false;
+    if (c.zsep) return false;            // the axis-0-separable box kernel reuses in-plane partial sums: 4 / 16 LDS reads per voxel
+    int T[3];
+    block_tile(&T[0], &T[1], &T[2]);
+    int L[3];
+    for (int r = 0; r < 3; ++r) {
+        double ext = 0;
+        for (int k = 0; k < 3; ++k) ext += std::fabs(m[4 * r + k]) * (T[k] - 1);
+        if (!(ext < 256.0)) return false;
+        L[r] = (int)std::floor(ext) + 3 + c.halo2;           // floor(hi)-floor(lo) <= floor(ext)+1, +1 upper tap, +1 slack
+    }
+    const int lx_used = (L[2] + 3 + 3) & ~3;                 // origin aligned down by up to 3, whole vectors
+    int rs_idx = -1;
+    for (int i = 0; i < block_rs_count() && rs_idx < 0; ++i)
+        if (block_rs(i) >= lx_used) rs_idx = i;
+    if (v->tune.block_rs >= 0 && v->tune.block_rs < block_rs_count() && block_rs(v->tune.block_rs) >= lx_used) rs_idx = v->tune.block_rs;
+    if (rs_idx < 0) return false;
+    const int RS = block_rs(rs_idx);
+    const int lm = v->tune.block_lm >= 0 ? v->tune.block_lm : 0;
+    // plane stride: the padding (whole vectors, one bank period) with the fewest predicted gather conflicts
+    int best_pad = 0;
+    double best_f = 1e300;
+    for (int pad = 0; pad < 64; pad += 4) {
+        const double f = block_conflicts(m, lm, RS, L[1] * RS + pad, c.cubic) * (1.0 + 0.002 * pad);
+        if (f < best_f - 1e-9) { best_f = f; best_pad = pad; }
+    }
+    if (v->tune.block_pad >= 0) best_pad = v->tune.block_pad & ~3;
+    const int PS = L[1] * RS + best_pad;
+    const int64_t vectors = (int64_t)L[0] * PS / 4;
+    if (vectors > block_max_vectors()) return false;
+    const int64_t plane_b = (int64_t)v->H * v->P * 4;
+    if ((int64_t)L[0] * plane_b >= 0x7fffffffLL || (int64_t)T[0] * v->oH * v->oW * 4 >= 0x7fffffffLL) return false;
+    const int lds_bytes = (int)((vectors + 63) / 64 * 64 * 16);
+    if (lds_bytes > v->lds_limit) return false;
+
+    plan->kind = 9; plan->cfg = rs_idx; plan->lm = lm; plan->td = T[0]; plan->th = T[1]; plan->tw = T[2];
+    plan->lds_bytes = lds_bytes;
+    p->Lz = L[0]; p->Ly = L[1]; p->Lx = RS; p->Lx_used = lx_used; p->Lps = PS;
+    p->flags = (c.flags & VT_KEEP_OUTSIDE) | experiment_flags(v);
+    set_tile_reach(p, m, T, 0);
+    p->nTd = (v->oD + T[0] - 1) / T[0];
+    p->nTh = (v->oH + T[1] - 1) / T[1];
+    p->nTw = (v->oW + T[2] - 1) / T[2];
+    // steps between a thread's four voxels (Gray order): lm 0: w+8, d+4, w-8;  lm 1: h+4, d+4, h-4
+    const int col[3] = {lm == 0 ? 2 : 1, 0, lm == 0 ? 2 : 1};
+    const double mul[3] = {lm == 0 ? 8.0 : 4.0, 4.0, lm == 0 ? -8.0 : -4.0};
+    for (int s = 0; s < 3; ++s)
+        for (int r = 0; r < 3; ++r) {
+            const double step = m[4 * r + col[s]] * mul[s];
+            const double fl = std::floor(step);
+            double lo = std::floor((step - fl) * 4294967296.0 + 0.5);
+            int32_t hi = (int32_t)fl;
+            if (lo >= 4294967296.0) { lo = 0; hi += 1; }
+            p->binc_hi[s][r] = hi; p->binc_lo[s][r] = (uint32_t)lo;
+        }
+    // the forward and the backward step along the repeated axis must cancel exactly: derive step 2 from step 0
+    for (int r = 0; r < 3; ++r) {
+        const uint64_t fwd = ((uint64_t)(uint32_t)p->binc_hi[0][r] << 32) | p->binc_lo[0][r];
+        const uint64_t back = 0 - fwd;
+        p->binc_hi[2][r] = (int32_t)(uint32_t)(back >> 32); p->binc_lo[2][r] = (uint32_t)back;
+    }
+    const int64_t grid = blocked_tile_count(p->nTd, p->nTh, p->nTw) / 8;      // one workgroup per brick of 2 x 2 x 2 tiles
+    plan->blocks_per_cu = block_blocks_per_cu(rs_idx, v->interp, lm, lds_bytes);
+    plan->grid = (int)grid;
+    return true;
+}
+
 // box and packed compete on staged bytes per voxel
 bool plan_general(PlanCtx& c)
 {
@@ -771,6 +875,7 @@ const Family kFamilies[] = {
     {"quad", plan_quad},        // axis-0-separable, plane-quad layout
     {"zpair", plan_zpair},      // axis-0-separable cubic, plane-pair layout
     {"march", plan_march},      // axis-0-separable, plain layout
+    {"block", plan_block},      // 3-D tiles: lane blocks on a bank-tuned box (rotations, mild scale / shear)
     {"general", plan_general},  // 3-D tiles: bounding boxes vs packed footprints
 };
 
