@@ -95,7 +95,7 @@ def test_tiled_and_direct_match_oracle(interp, mname, shape):
         assert 2 in kernels and 1 in kernels
     if mname in ('rot_general', 'shear', 'rot_scale_shift', 'minify', 'mirror'):
         assert 6 in kernels                          # packed-footprint kernel for invertible general matrices
-    if mname in ('rot_general', 'shear', 'rot_scale_shift', 'mirror', 'rot_axis1', 'rot_axis2_shift', 'rot_inplane45', 'shift_frac'):
+    if interp != 'linear' and mname in ('rot_general', 'shear', 'rot_scale_shift', 'mirror', 'rot_axis1', 'rot_axis2_shift', 'rot_inplane45', 'shift_frac'):
         assert 9 in kernels                          # lane-block kernel: every matrix whose tile footprint fits its LDS rows
 
 
@@ -147,7 +147,8 @@ def test_default_dispatch_uses_tiled_kernel_on_large_volumes(interp):
     vol = rand_vol(shape, 2)
     m = MATRICES['rot_general'](shape)
     got, info = run_case(vol, m, interp)
-    assert info.last_kernel == 9 and info.last_lds_bytes > 0          # general matrices: the lane-block kernel
+    # general matrices: cubic interpolations on the lane-block kernel; trilinear on boxes (too few tiles for packed footprints)
+    assert info.last_kernel == (2 if interp == 'linear' else 9) and info.last_lds_bytes > 0
     assert np.abs(got - oracle.affine(vol, m, interp)).max() <= TOL[interp]
     got, info = run_case(vol, m, interp, _native.NO_BLOCK)
     # a volume this small has too few tiles to amortise the packed kernel's per-workgroup set-up: bounding boxes
@@ -555,7 +556,7 @@ def test_full_size_properties_512(interp):
     m = vt.utils.transform_matrix(rotation=(25, -40, 70), rotation_order='sxyz', center=centre((n, n, n)))
     sv.affine(m, output=out)
     a = out.get()
-    assert sv.info().last_kernel == 9
+    assert sv.info().last_kernel == (6 if interp == 'linear' else 9)     # trilinear: packed footprints; cubic: lane blocks
     sv.affine(m, output=out, _flags=_native.FORCE_DIRECT)
     b = out.get()
     assert np.abs(a - b).max() <= tol
@@ -572,7 +573,7 @@ def test_full_size_properties_512(interp):
         a = out.get()
         assert sv.info().last_kernel == 8 or (rot[2] and interp == 'linear'), rot
         sv.affine(m, output=out, _flags=_native.NO_ZSEP)
-        assert sv.info().last_kernel == 9
+        assert sv.info().last_kernel == (9 if interp != 'linear' else sv.info().last_kernel)
         assert np.abs(a - out.get()).max() <= tol, rot
         sv.affine(m, output=out, _flags=_native.NO_ZSEP | _native.NO_BLOCK)
         assert sv.info().last_kernel in (2, 6)
@@ -594,7 +595,7 @@ def test_full_size_properties_512(interp):
     assert sv.info().last_kernel == 3
     assert np.abs(a - out.get()).max() <= tol
     sv.affine(m, output=out, _flags=_native.NO_ZSEP)
-    assert sv.info().last_kernel == 9
+    assert sv.info().last_kernel == (2 if interp == 'linear' else 9)
     assert np.abs(a - out.get()).max() <= tol
     sv.affine(m, output=out, _flags=_native.NO_ZSEP | _native.NO_BLOCK)
     assert sv.info().last_kernel == 2
@@ -739,3 +740,22 @@ def test_slab_volume_single_rank_process_group():
         sv.close()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('interp', ['linear', 'bspline_simple'])
+def test_lane_block_kernel_all_paths(interp, monkeypatch):
+    """Kernel 9 on shapes with partial tiles, boxes that leave the volume (checked staging), keep_outside and -- through the
+    VT_BLOCK_LINEAR switch, read at create -- its trilinear instantiation, which the planner does not pick by itself."""
+    monkeypatch.setenv('VT_BLOCK_LINEAR', '1')
+    for shape in ((70, 66, 72), (33, 47, 50), (130, 40, 97)):
+        vol = rand_vol(shape, 3)
+        for mname in ('rot_general', 'rot_scale_shift', 'shear', 'mirror', 'rot_axis2_shift'):
+            m = MATRICES[mname](shape)
+            want = oracle.affine(vol, m, interp)
+            got, info = run_case(vol, m, interp, _native.FORCE_TILED | _native.NO_ZSEP)
+            assert info.last_kernel == 9, (shape, mname, info.last_kernel)
+            assert np.abs(got - want).max() <= TOL[interp], (shape, mname)
+            init = rand_vol(shape, 4)
+            got, info = run_case(vol, m, interp, _native.FORCE_TILED | _native.NO_ZSEP, keep=True, out_init=init)
+            assert info.last_kernel == 9
+            assert np.abs(got - oracle.affine(vol, m, interp, oracle.KEEP_OUTSIDE, output=init.copy())).max() <= TOL[interp], (shape, mname, 'keep')

@@ -551,7 +551,11 @@ int launch_planned(vt_volume* v, const TilePlan& plan, const AffineParams& p, co
         }
         VT_HIP(launch_affine_zpair(plan.cfg, v->interp, *ori.pair_slot, d_out, p, plan.grid, plan.lds_bytes, v->stream));
     } else if (plan.kind == 9) {
-        VT_HIP(launch_affine_block(plan.cfg, v->interp, plan.lm, v->d_src, d_out, v->d_zeros, p, plan.grid, plan.lds_bytes, v->stream));
+        if (!v->d_queue) {
+            VT_HIP(hipMalloc(reinterpret_cast<void**>(&v->d_queue), 9 * 128));
+            VT_HIP(hipMemsetAsync(v->d_queue, 0, 9 * 128, v->stream));
+        }
+        VT_HIP(launch_affine_block(plan.cfg, v->interp, v->d_src, d_out, v->d_zeros, v->d_queue, p, plan.grid, plan.lds_bytes, v->stream));
     } else if (plan.kind == 6) {
         VT_HIP(launch_affine_packed(plan.cfg, v->interp, v->d_src, d_out, v->d_zeros, p, plan.geo, plan.grid, plan.lds_bytes, v->stream));
     } else if (plan.kind == 4) {
@@ -1313,6 +1317,7 @@ int vt_volume_destroy(vt_volume_t* v)
     hipSetDevice(v->dev);
     if (v->stream) hipStreamSynchronize(v->stream);
     if (v->d_src) cached_free(v->dev, v->d_src, v->src_bytes);
+    if (v->d_queue) hipFree(v->d_queue);
     if (v->d_src_zp) hipFree(v->d_src_zp);
     if (v->d_src_t) hipFree(v->d_src_t);
     if (v->d_src_t_zp) hipFree(v->d_src_t_zp);

@@ -26,7 +26,7 @@ struct Tuning {
     int quad_nt = -1;              // VT_QUAD_NT: 1 / 0 = nontemporal / plain output stores of the plane-quad kernel, -1 = planner's choice
     bool no_block = false;         // VT_NO_BLOCK_KERNEL: general matrices on the round-1 box / packed kernels
     int block_rs = -1;             // VT_BLOCK_RS: force the row-stride index of the lane-block kernel (if it holds the box)
-    int block_lm = -1;             // VT_BLOCK_LM: lane map of the lane-block kernel (0 = 4x4x4 blocks, 1 = rows of 16)
+    bool block_linear = false;     // VT_BLOCK_LINEAR: trilinear general matrices on the lane-block kernel too (slower than packed footprints)
     int block_pad = -1;            // VT_BLOCK_PAD: plane-stride padding in floats instead of the bank model's choice
     void read()
     {
@@ -50,8 +50,7 @@ struct Tuning {
         quad_rows = num("VT_QUAD_ROWS", -2);
         no_block = std::getenv("VT_NO_BLOCK_KERNEL") != nullptr;
         block_rs = num("VT_BLOCK_RS", -1);
-        block_lm = num("VT_BLOCK_LM", -1);
-        if (block_lm > 1) block_lm = 1;
+        block_linear = std::getenv("VT_BLOCK_LINEAR") != nullptr;
         block_pad = num("VT_BLOCK_PAD", -1);
     }
 };
@@ -86,6 +85,7 @@ struct vt_volume {
     float* d_src_x_q = nullptr;
     size_t quad_bytes[4] = {0, 0, 0, 0};   // allocation sizes of the four quad copies (vt_volume_info)
     int P2 = 0;                        // floats per pair-row of d_src_zp
+    int* d_queue = nullptr;            // lane-block kernel: tile counters (one per XCD + a departure count), zero between launches
     float* d_scratch_out = nullptr;    // staging for host outputs
     double* d_batch_m = nullptr;       // batch launches: n x 12 folded matrices
     std::vector<double> h_batch_m;     // ... and their host staging (must outlive the asynchronous upload)

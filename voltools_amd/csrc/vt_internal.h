@@ -49,8 +49,10 @@ struct AffineParams {
     int32_t dshift;            // plane-quad kernel: chunk c > 0 starts at output plane c*dch + dshift (0..3), chosen so that a chunk's first
                                // tap plane is the first plane of a quad (one quad step per chunk beyond its own planes instead of two)
     int32_t Lps;               // block kernel: LDS plane stride in floats (Ly * row stride + bank padding, multiple of 4)
-    int32_t binc_hi[3][3];     // block kernel: Q32.32 increments of the three steps between a thread's four voxels, [step][source axis]
-    uint32_t binc_lo[3][3];
+    uint32_t psv_magic;        // block kernel: floor(2^32 / (Lps / 4)) + 1
+    int32_t lds_cap;           // block kernel: bytes of LDS the box may take (the tile-queue word follows)
+    int32_t binc_hi[5][3];     // block kernel: Q32.32 increments of the steps between a thread's eight voxels (+8 w, +8 h, -8 w, +4 d, -8 h),
+    uint32_t binc_lo[5][3];    // [step kind][source axis]
 };
 
 
@@ -122,8 +124,7 @@ struct PackGeom {
 
 struct TilePlan {
     int kind;            // 1 direct, 2 tiled, 3 tiled axis-0-separable, 4 marching, 5 marching on plane pairs, 6 tiled with packed footprints,
-                         // 8 marching on plane quads, 9 lane-block tiles (cfg = row-stride index, lm = lane map)
-    int lm;
+                         // 8 marching on plane quads, 9 lane-block tiles (cfg = row-stride index)
     int cfg;             // index into the tile table
     int td, th, tw;
     int lds_bytes;
@@ -223,9 +224,8 @@ int block_rs_count();
 int block_rs(int idx);
 int block_max_vectors();
 void block_tile(int* td, int* th, int* tw);
-int block_blocks_per_cu(int rs_idx, int interp, int lm, int lds_bytes);
 hipError_t init_block_kernels();
-hipError_t launch_affine_block(int rs_idx, int interp, int lm, const float* src, float* out, const float* zeros16,
+hipError_t launch_affine_block(int rs_idx, int interp, const float* src, float* out, const float* zeros16, int* queue,
                                const AffineParams& p, int grid, int lds_bytes, hipStream_t stream);
 int packed_config_count();
 void packed_config(int idx, int* td, int* th, int* tw);

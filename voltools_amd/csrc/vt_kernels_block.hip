@@ -1,24 +1,29 @@
 // vt_kernels_block.hip -- general matrices (true 3-D rotations, the reference's own benchmark protocol, tests/benchmark.py:52-54):
-// 8 x 8 x 16 output tiles gathered from a bank-tuned LDS box by compact lane blocks (kernel id 9, gfx950).
+// 8 x 16 x 16 output tiles gathered from a bank-tuned LDS box by compact lane blocks (kernel id 9, gfx950).
 //
-// What bounded the bounding-box kernel (`affine_tiled`, vt_kernels_affine.hip) on 512^3 cubic rotations was neither HBM nor LDS
-// bytes but instruction issue: 327 wave-instructions per 64 voxels (234 VALU, 38-48 LDS, 40 SALU), SQ_ACTIVE_INST_ANY = 90 % of
-// the run time (profiles/r02_general512_cubic_summary.json), plus a gather conflict degree of 2.1 on the LDS side.  This kernel is
-// the same algorithm with the instruction stream and the LDS image designed together:
+// What bounded the bounding-box kernel (`affine_tiled`, vt_kernels_affine.hip) on 512^3 cubic rotations was instruction issue: 327
+// wave-instructions per 64 voxels (234 VALU, 38-48 LDS, 40 SALU), SQ_ACTIVE_INST_ANY = 90 % of the run time
+// (profiles/r02_general512_cubic_summary.json), with an LDS conflict degree of 2.1 beside it.  This kernel is the same algorithm with
+// the instruction stream and the LDS image designed together:
 //   * the LDS row stride RS is a template constant: the 16 tap rows x 3 eight-byte reads of a cubic voxel are immediates off
 //     8 address registers (4 planes x {first two pairs, third pair}) instead of 32 computed addresses;
-//   * the 64 taps are summed as 48 packed FMAs (v_pk_fma_f32) on the pairs as they come back from `ds_read_b64`:
+//   * the 64 taps are summed as 48 packed FMAs (v_pk_fma_f32) on the pairs as `ds_read_b64` returns them:
 //     S_k += (wz_c * wy_b) * pair_k(c, b), k = 0..2, then the six parity-shifted x weights once per voxel;
 //   * a 32-lane group of `ds_read_b64` is a 2 x 4 x 4 block of output voxels, not 2 rows of 16: its taps sit in a compact source
 //     neighbourhood, and the plane stride (a run-time value: Ly * RS + pad) is chosen per matrix by the host's bank model so that
-//     this neighbourhood spreads over the 32 bank pairs (tools/gather_b64_sim.py: conflict degree 1.6 instead of 2.2);
-//   * workgroups are persistent and keep the box-relative source offset of each of their staging vectors in registers: staging a
-//     tile is one `buffer_load ... lds` per 16-byte vector and nothing else (box wholly inside the volume; the checked path
-//     serves tiles at the border);
-//   * coordinates step in Q32.32 between the four voxels of a thread (Gray order: one increment per step), output offsets are a
+//     this neighbourhood spreads over the 32 bank pairs (tools/gather_b64_sim.py: conflict degree 1.6 instead of 2.2; measured 1.59);
+//   * a workgroup serves a brick of 2 x 2 x 2 tiles and keeps the box-relative source offset of each of its staging vectors in
+//     registers: staging a tile is one `buffer_load ... lds` per 16-byte vector and nothing else (box wholly inside the volume; the
+//     checked path serves tiles at the border);
+//   * coordinates step in Q32.32 between the eight voxels of a thread (Gray order: one increment per step), output offsets are a
 //     per-thread register plus a per-step scalar.
 // The arithmetic differs from `affine_tiled` only in the association of the 64-term sum (pairs, then x), i.e. by float32
-// rounding of a convex combination; tests hold it to the same tolerance against the oracle.
+// rounding of a convex combination; tests hold it to the same tolerance against the oracle.  A non-finite source value reaches
+// every output whose aligned 6-wide x window contains it (two columns more than the 4-tap stencil).
+// Measured limits of the design (profiles/r02_ablate_block_*.txt): staging moves 36 bytes per voxel through
+// the CU's vector-memory path (~70 GB/s per CU from L2); the gather itself is VALU-bound (~120 per 64 voxels).  A variant that
+// staged per-plane footprint rectangles instead of the box (4.6 instead of 8.9 floats per voxel) was correct and slower: its
+// per-tile set-up (one lane per plane cutting the rotated tile by a slab) and 65536 short workgroups cost more than the bytes saved.
 #include "vt_internal.h"
 #include "vt_device.h"
 
@@ -28,8 +33,9 @@ namespace vt {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-constexpr int kBlkTD = 8, kBlkTH = 8, kBlkTW = 16;
-constexpr int kBlkMaxIt = 16;                 // staging vectors per thread: boxes up to 4096 vectors = 64 KiB
+constexpr int kBlkTD = 8, kBlkTH = 16, kBlkTW = 16;
+constexpr int kBlkChunk = 4;                  // tile ids per queue fetch
+constexpr int kBlkMaxIt = 20;                 // staging vectors per thread: boxes up to 5120 vectors = 80 KiB
 
 template <int OFF>
 __device__ __forceinline__ void lds_read_b64(v2f& r, unsigned a)
@@ -109,11 +115,9 @@ __device__ __forceinline__ void stage_block_checked(float* lds, const float* __r
     }
 }
 
-// LM: lane -> voxel map.  0: a wave is a 4 x 4 x 4 block (32-lane groups 2 x 4 x 4), the workgroup 4 x 8 x 8, steps w+8, d+4, w-8.
-//                         1: a wave is 4 rows of 16 (32-lane groups 2 x 16), the workgroup 4 x 4 x 16, steps h+4, d+4, h-4.
-template <int KIND, int RS, int LM>
-__global__ __launch_bounds__(256, KIND == 0 ? 5 : 3) void affine_block(const float* __restrict__ src, float* __restrict__ out,
-                                                     const float* __restrict__ zeros16, const AffineParams p)
+template <int KIND, int RS>
+__global__ __launch_bounds__(256, 2) void affine_block(const float* __restrict__ src, float* __restrict__ out,
+                                                        const float* __restrict__ zeros16, int* __restrict__ queue, const AffineParams p)
 {
     constexpr bool CUBIC = KIND != 0;
     constexpr int HALO = CUBIC ? 1 : 0;
@@ -123,12 +127,13 @@ __global__ __launch_bounds__(256, KIND == 0 ? 5 : 3) void affine_block(const flo
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wave_first = __builtin_amdgcn_readfirstlane(tid & ~63);
-    int vd, vh, vw;
-    if constexpr (LM == 0) { vd = lane >> 4; vh = 4 * (wv >> 1) + ((lane >> 2) & 3); vw = 4 * (wv & 1) + (lane & 3); }
-    else { vd = wv; vh = lane >> 4; vw = lane & 15; }
-    constexpr int sd[4] = {0, 0, 4, 4};
-    constexpr int sh[4] = {0, LM == 0 ? 0 : 4, LM == 0 ? 0 : 4, 0};
-    constexpr int sw[4] = {0, LM == 0 ? 8 : 0, LM == 0 ? 8 : 0, 0};
+    // a wave is a 4 x 4 x 4 block of voxels (32-lane groups 2 x 4 x 4), the workgroup 4 x 8 x 8; the eight voxels of a thread in
+    // Gray order: w+8, h+8, w-8, d+4, w+8, h-8, w-8
+    const int vd = lane >> 4, vh = 4 * (wv >> 1) + ((lane >> 2) & 3), vw = 4 * (wv & 1) + (lane & 3);
+    constexpr int sd[8] = {0, 0, 0, 0, 4, 4, 4, 4};
+    constexpr int sh[8] = {0, 0, 8, 8, 8, 8, 0, 0};
+    constexpr int sw[8] = {0, 8, 8, 0, 0, 8, 8, 0};
+    constexpr int which[7] = {0, 1, 2, 3, 0, 4, 2};              // increments: +w8, +h8, -w8, +d4, -h8
 
     const int Lz = p.Lz, Ly = p.Ly, ps = p.Lps;
     const int psv = ps >> 2;
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(256, KIND == 0 ? 5 : 3) void affine_block(const flo
 #pragma unroll
     for (int k = 0; k < kBlkMaxIt; ++k) {
         const int v = k * 256 + tid;
-        const int z = v / psv, rem = v - z * psv;
+        const int z = (int)__umulhi((unsigned)v, p.psv_magic), rem = v - z * psv;      // v / psv (v * psv < 2^32)
         const int y = rem / nvx, cx = rem - y * nvx;
         voff[k] = (v < total && y < Ly && cx < nvx_used) ? z * plane_b + y * row_b + 16 * cx : 0;
     }
@@ -150,9 +155,7 @@ __global__ __launch_bounds__(256, KIND == 0 ? 5 : 3) void affine_block(const flo
     const bool keep = (p.flags & VT_KEEP_OUTSIDE) != 0;
     const int64_t ostride = (int64_t)p.oH * p.oW;
     const int obase = (int)((vd * ostride + (int64_t)vh * p.oW + vw) * 4);     // TD * ostride * 4 < 2^31 (host-checked)
-    int ostep[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) ostep[s] = (int)((sd[s] * ostride + (int64_t)sh[s] * p.oW + sw[s]) * 4);
+    const int ostep_d = (int)(4 * ostride * 4), ostep_h = (int)(8 * (int64_t)p.oW * 4);
     const unsigned ps4 = 4u * (unsigned)ps;
     const unsigned lds_base = lds_byte_address(lds);
 #ifdef VT_EXPERIMENTS      // make EXTRA=-DVT_EXPERIMENTS: VT_EXP_NOSTORE / VT_EXP_NOLOAD / VT_EXP_NOLDS ablations
@@ -161,22 +164,37 @@ __global__ __launch_bounds__(256, KIND == 0 ? 5 : 3) void affine_block(const flo
     constexpr bool no_stores = false, no_loads = false, no_lds = false;
 #endif
 
-    // A workgroup serves a brick of 2 x 2 x 2 tiles (the staging offsets above are computed once for eight tiles); bricks are
-    // dispatched by the hardware in id order, so the workgroups in flight on one XCD (blockIdx % 8) always form a compact window
-    // of consecutive bricks whose overlapping boxes meet in that XCD's L2 -- with statically strided persistent workgroups the
-    // window frays as soon as some workgroups meet cheap tiles (outside the volume), and the L2 hit rate of the staging loads
-    // fell to 0.62 (8 bytes fetched beyond L2 per algorithmic byte).  Brick ids: 4 x 4 x 4 tiles per super-block, w fastest.
-    const int nbricks = blocked_tile_count(p.nTd, p.nTh, p.nTw) >> 3;
-    const int brick = xcd_contiguous(blockIdx.x, nbricks);
-    const int nSh = (p.nTh + 3) >> 2, nSw = (p.nTw + 3) >> 2;
-    const int sb = brick >> 3, bq = brick & 7;
-    const int sbw = sb % nSw, sb2 = sb / nSw;
-    const int sbh = sb2 % nSh, sbd = sb2 / nSh;
-    for (int t = 0; t < 8; ++t) {
-        const int td_i = sbd * 4 + 2 * (bq >> 2) + (t >> 2);
-        const int th_i = sbh * 4 + 2 * ((bq >> 1) & 1) + ((t >> 1) & 1);
-        const int tw_i = sbw * 4 + 2 * (bq & 1) + (t & 1);
-        if (td_i >= p.nTd || th_i >= p.nTh || tw_i >= p.nTw) continue;
+    // Tiles are handed out from one counter per XCD (blockIdx % 8 is the XCD of a workgroup; each XCD owns a contiguous range of tile
+    // ids, 4 x 4 x 4 tiles per super-block, w fastest): the tiles in flight on an XCD are always the most recent consecutive ids,
+    // a compact patch of the volume whose overlapping boxes meet in that XCD's 4 MiB L2, while the workgroups stay persistent and
+    // keep their staging offsets.  (Static striding frays the patch as soon as some workgroups meet cheap tiles outside the
+    // volume -- L2 hit rate of the staging loads 0.62; bricks of 8 tiles per workgroup put 64 far-apart tiles in flight per XCD.)
+    // The id of the next tile is fetched while the current one is gathered.  The last workgroup to leave zeroes the counters.
+    int* const ctrl = reinterpret_cast<int*>(lds + (p.lds_cap >> 2));      // one word behind the box
+    const int nids = blocked_tile_count(p.nTd, p.nTh, p.nTw);
+    const int xcd = blockIdx.x & 7, per = ((nids >> 6) + 7) / 8 * 64;      // whole super-blocks per XCD
+    const int id0 = xcd * per, id_cnt = max(0, min(per, nids - id0));
+    // one counter per XCD, each on a cache line of its own; a fetch hands out kBlkChunk consecutive ids
+    int* const counter = queue + 32 * xcd;
+    int nxt = 0;
+    if (tid == 0) nxt = atomicAdd(counter, kBlkChunk);
+    int cur = 0, left = 0;
+    for (;;) {
+        if (left == 0) {
+            if (tid == 0) ctrl[0] = nxt;
+            __syncthreads();                                     // the next chunk is visible
+            cur = ctrl[0];
+            left = kBlkChunk;
+            __syncthreads();                                     // everyone has read it before thread 0 may overwrite it
+            if (cur >= id_cnt) break;
+            if (tid == 0) nxt = atomicAdd(counter, kBlkChunk);
+        }
+        const int id = id0 + cur;
+        ++cur; --left;
+        if (cur > id_cnt) continue;
+        int td_i, th_i, tw_i;
+        const bool tile_ok = blocked_tile(id, p.nTd, p.nTh, p.nTw, td_i, th_i, tw_i);
+        if (!tile_ok) continue;
         const int d0 = td_i * TD, h0 = th_i * TH, w0 = tw_i * TW;
 
         // ---- tile geometry (wave-uniform, float64) ----
@@ -198,10 +216,10 @@ __global__ __launch_bounds__(256, KIND == 0 ? 5 : 3) void affine_block(const flo
             // the whole tile maps outside the valid interval: zero-fill (or leave untouched)
             if (!keep) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
+                for (int s = 0; s < 8; ++s) {
                     const int d = d0 + vd + sd[s], h = h0 + vh + sh[s], w = w0 + vw + sw[s];
                     if (whole || (d < p.oD && h < p.oH && w < p.oW))
-                        __builtin_amdgcn_raw_buffer_store_b32(0u, orsrc, obase, ostep[s], 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(0u, orsrc, obase, (sd[s] >> 2) * ostep_d + (sh[s] >> 3) * ostep_h + 4 * sw[s], 0);
                 }
             }
             continue;
@@ -226,17 +244,18 @@ __global__ __launch_bounds__(256, KIND == 0 ? 5 : 3) void affine_block(const flo
         } else {
             stage_block_checked<RS>(lds, src, zeros16, p, o, total, psv, nvx_used, tid);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-
-        // ---- gather ----
+        // this thread's first voxel, box coordinates in Q32.32 (while the loads are in flight)
         Fx c[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r)
             c[r] = to_fx(fma(p.m[4 * r], (double)vd, fma(p.m[4 * r + 1], (double)vh, fma(p.m[4 * r + 2], (double)vw, base[r] - (double)o[r]))));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        // ---- gather ----
         const bool fast = all_valid && whole;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < 8; ++s) {
             float val;
             if (no_lds) {
                 val = fx_frac(c[0]) + fx_frac(c[1]) + fx_frac(c[2]);
@@ -258,24 +277,32 @@ __global__ __launch_bounds__(256, KIND == 0 ? 5 : 3) void affine_block(const flo
                 const float y1 = fmaf(fy, x11 - x10, x10);
                 val = fmaf(fz, y1 - y0, y0);
             }
+            const int soff = (sd[s] >> 2) * ostep_d + (sh[s] >> 3) * ostep_h + 4 * sw[s];
             if (no_stores) {
-                if (val == 123.456f) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), orsrc, obase, ostep[s], 0);
+                if (val == 123.456f) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), orsrc, obase, soff, 0);
             } else if (fast) {
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), orsrc, obase, ostep[s], 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), orsrc, obase, soff, 0);
             } else {
                 // tiles cut by the skirt or by the end of the output: the inside test is the canonical float64 chain
                 const int d = d0 + vd + sd[s], h = h0 + vh + sh[s], w = w0 + vw + sw[s];
                 if (d < p.oD && h < p.oH && w < p.oW) {
                     const bool inside = canonical_inside(p, d, h, w);
-                    if (inside) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), orsrc, obase, ostep[s], 0);
-                    else if (!keep) __builtin_amdgcn_raw_buffer_store_b32(0u, orsrc, obase, ostep[s], 0);
+                    if (inside) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), orsrc, obase, soff, 0);
+                    else if (!keep) __builtin_amdgcn_raw_buffer_store_b32(0u, orsrc, obase, soff, 0);
                 }
             }
-            if (s < 3) {
+            if (s < 7) {
 #pragma unroll
-                for (int r = 0; r < 3; ++r) fx_step(c[r], p.binc_hi[s][r], p.binc_lo[s][r]);
+                for (int r = 0; r < 3; ++r) fx_step(c[r], p.binc_hi[which[s]][r], p.binc_lo[which[s]][r]);
             }
-            __builtin_amdgcn_sched_barrier(0);                   // one voxel's weights and taps in registers at a time
+            // (no scheduling barrier: at 2 waves per SIMD the compiler may overlap the next voxel's weights with this one's taps)
+        }
+    }
+    if (tid == 0) {
+        __threadfence();
+        if (atomicAdd(&queue[256], 1) == (int)gridDim.x - 1) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) queue[32 * i] = 0;
         }
     }
 }
@@ -283,74 +310,41 @@ __global__ __launch_bounds__(256, KIND == 0 ? 5 : 3) void affine_block(const flo
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
-typedef void (*block_fn)(const float*, float*, const float*, const AffineParams);
+typedef void (*block_fn)(const float*, float*, const float*, int*, const AffineParams);
 
-static const int kBlkRS[] = {20, 28, 36};
+static const int kBlkRS[] = {28, 36};
 int block_rs_count() { return (int)(sizeof(kBlkRS) / sizeof(kBlkRS[0])); }
 int block_rs(int idx) { return kBlkRS[idx]; }
 int block_max_vectors() { return 256 * kBlkMaxIt; }
 void block_tile(int* td, int* th, int* tw) { *td = kBlkTD; *th = kBlkTH; *tw = kBlkTW; }
 
-template <int RS, int LM>
+template <int RS>
 static block_fn pick_block_kind(int kind)
 {
     switch (kind) {
-        case 0: return affine_block<0, RS, LM>;
-        case 1: return affine_block<1, RS, LM>;
-        default: return affine_block<2, RS, LM>;
+        case 0: return affine_block<0, RS>;
+        case 1: return affine_block<1, RS>;
+        default: return affine_block<2, RS>;
     }
 }
 
-static block_fn block_entry(int rs_idx, int kind, int lm)
-{
-    if (lm == 0) {
-        switch (rs_idx) {
-            case 0: return pick_block_kind<20, 0>(kind);
-            case 1: return pick_block_kind<28, 0>(kind);
-            default: return pick_block_kind<36, 0>(kind);
-        }
-    }
-    switch (rs_idx) {
-        case 0: return pick_block_kind<20, 1>(kind);
-        case 1: return pick_block_kind<28, 1>(kind);
-        default: return pick_block_kind<36, 1>(kind);
-    }
-}
+static block_fn block_entry(int rs_idx, int kind) { return rs_idx == 0 ? pick_block_kind<28>(kind) : pick_block_kind<36>(kind); }
 
 hipError_t init_block_kernels()
 {
     for (int rs = 0; rs < block_rs_count(); ++rs)
-        for (int kind = 0; kind < 3; ++kind)
-            for (int lm = 0; lm < 2; ++lm) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(block_entry(rs, kind, lm)),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (e != hipSuccess) return e;
-            }
+        for (int kind = 0; kind < 3; ++kind) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(block_entry(rs, kind)),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+        }
     return hipSuccess;
 }
 
-// resident workgroups per CU (registers and LDS), cached per (kernel, LDS bytes rounded up to 4 KiB)
-int block_blocks_per_cu(int rs_idx, int interp, int lm, int lds_bytes)
-{
-    static int cache[3][3][2][41] = {};
-    const int kind = interp_kind(interp);
-    const int slot = std::min(40, (lds_bytes + 4095) / 4096);
-    int& c = cache[rs_idx][kind][lm][slot];
-    if (c == 0) {
-        int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(block_entry(rs_idx, kind, lm)), 256, (size_t)slot * 4096) != hipSuccess || n < 1) {
-            (void)hipGetLastError();
-            n = 1;
-        }
-        c = n;
-    }
-    return c;
-}
-
-hipError_t launch_affine_block(int rs_idx, int interp, int lm, const float* src, float* out, const float* zeros16,
+hipError_t launch_affine_block(int rs_idx, int interp, const float* src, float* out, const float* zeros16, int* queue,
                                const AffineParams& p, int grid, int lds_bytes, hipStream_t stream)
 {
-    hipLaunchKernelGGL(block_entry(rs_idx, interp_kind(interp), lm), dim3(grid), dim3(256), lds_bytes, stream, src, out, zeros16, p);
+    hipLaunchKernelGGL(block_entry(rs_idx, interp_kind(interp)), dim3(grid), dim3(256), lds_bytes, stream, src, out, zeros16, queue, p);
     return hipGetLastError();
 }
 
