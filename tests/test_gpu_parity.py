@@ -147,7 +147,10 @@ def test_default_dispatch_uses_tiled_kernel_on_large_volumes(interp):
     vol = rand_vol(shape, 2)
     m = MATRICES['rot_general'](shape)
     got, info = run_case(vol, m, interp)
-    # general matrices: cubic interpolations on the lane-block kernel; trilinear on boxes (too few tiles for packed footprints)
+    # a volume this small has too few tiles for the persistent lane-block kernel; forced, cubic interpolations take it
+    assert info.last_kernel == 2 and info.last_lds_bytes > 0
+    assert np.abs(got - oracle.affine(vol, m, interp)).max() <= TOL[interp]
+    got, info = run_case(vol, m, interp, _native.FORCE_TILED)
     assert info.last_kernel == (2 if interp == 'linear' else 9) and info.last_lds_bytes > 0
     assert np.abs(got - oracle.affine(vol, m, interp)).max() <= TOL[interp]
     got, info = run_case(vol, m, interp, _native.NO_BLOCK)
