@@ -93,6 +93,11 @@ __global__ __launch_bounds__(256) void affine_tiled_packed(const float* __restri
     const int kw = tid % TW;
     const int jh0 = tid / TW;
     const bool fits = (nvec * 4 <= p.Lx) && (nvec <= 256 * kPackMaxIt);  // p.Lx = footprint buffer capacity in floats
+#ifdef VT_EXPERIMENTS      // make EXTRA=-DVT_EXPERIMENTS: VT_EXP_NOSTORE / VT_EXP_NOLOAD / VT_EXP_NOLDS ablations
+    const bool no_stores = (p.flags & (1 << 21)) != 0, no_loads = (p.flags & (1 << 22)) != 0, no_lds = (p.flags & (1 << 26)) != 0;
+#else
+    constexpr bool no_stores = false, no_loads = false, no_lds = false;
+#endif
 
     // row of every vector: each thread writes the entries of its own rows' vectors (no search afterwards); the list
     // overlays the footprint buffer, which is not in use yet
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(256) void affine_tiled_packed(const float* __restri
                             const bool inb = (unsigned)gz < (unsigned)p.sD && (unsigned)gy < (unsigned)p.sH && (unsigned)gx < (unsigned)p.sP;
                             g = inb ? g : zeros16;
                         }
-                        if (tid + 256 * it < nvec) lds_dma16(g, buf_addr + 16u * (unsigned)v0);
+                        if (tid + 256 * it < nvec && !no_loads) lds_dma16(g, buf_addr + 16u * (unsigned)v0);
                     }
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the direct-to-LDS loads are invisible to hipcc's counters
@@ -212,7 +217,9 @@ __global__ __launch_bounds__(256) void affine_tiled_packed(const float* __restri
                         const int iz = c0.hi, iy = c1.hi, ix = c2.hi;
                         const float fz = fx_frac(c0), fy = fx_frac(c1), fx = fx_frac(c2);
                         float val;
-                        if constexpr (!CUBIC) {
+                        if (no_lds) {
+                            val = fz + fy + fx;
+                        } else if constexpr (!CUBIC) {
                             const int* tr = rowbase + (__mul24(iz, Ly) + iy);
                             const float* r00 = buf + tr[0] + ix;
                             const float* r01 = buf + tr[1] + ix;
@@ -242,7 +249,8 @@ __global__ __launch_bounds__(256) void affine_tiled_packed(const float* __restri
                             val = cubic_gather_b64([&](int c, int bb) { return ba + 4u * (unsigned)roff[4 * c + bb]; }, par, wx, wy, wz);
                         }
                         const bool inside = all_valid || canonical_inside(p, d0 + i, h, w);
-                        if (inside) optr[i * ostride] = val;
+                        if (no_stores) { if (val == 123.456f) optr[i * ostride] = val; }
+                        else if (inside) optr[i * ostride] = val;
                         else if (!keep) optr[i * ostride] = 0.0f;
                         fx_step(c0, p.inc_hi[0], p.inc_lo[0]);
                         fx_step(c1, p.inc_hi[1], p.inc_lo[1]);

@@ -749,6 +749,7 @@ bool plan_packed(PlanCtx& c, bool have_box, double box_bpv)
     if (ntiles > 0x7fffffffLL) { c.plan->kind = 1; return true; }      // (as before: such a launch goes to the direct kernel)
     // persistent workgroups: as many as stay resident, a multiple of 8 (one share per XCD)
     if (v->tune.plain_tile_order) p->flags |= (1 << 23);
+    p->flags |= experiment_flags(v);
     int64_t nwg = std::min<int64_t>(ntiles, (int64_t)v->cu_count * std::max(1, c.plan->blocks_per_cu));
     nwg = std::max<int64_t>(8, (nwg + 7) / 8 * 8);
     c.plan->grid = (int)nwg;
