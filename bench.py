@@ -251,8 +251,8 @@ def main():
         # extra (not the headline): the linear kernel on the same volume, and the prefilter's own roofline
         extra = {}
         svl = vt.StaticVolume(vol, interpolation='linear', device=dev)
-        for i in range(3):
-            svl.affine(mats[i], output=out)
+        for i in range(args.steps):                  # one untimed pass: the lazily built resident copies (transposed, plane-quad) exist afterwards
+            svl.affine(mats[args.warmup + i], output=out)
         svl.synchronize()
         svl.timer_start()
         for i in range(args.steps):
@@ -274,7 +274,7 @@ def main():
                 cb = np.divide(np.subtract((1024, 1024, 1024), 1), 2, dtype=np.float32)
                 mb = [vt.utils.transform_matrix(rotation=(0, float(a), 0), rotation_units='deg', rotation_order='rzxz', center=cb)
                       for a in range(0, 180, 6)]
-                for m_ in mb[:3]:
+                for m_ in mb:                         # one untimed pass (builds the transposed / plane-quad copies the sweep uses)
                     svb.affine(m_, output=outb)
                 svb.synchronize()
                 svb.timer_start()

@@ -9,7 +9,11 @@ ap.add_argument('--interp', default='filt_bspline')
 ap.add_argument('--step', type=int, default=3)
 args = ap.parse_args()
 n = args.size
-vol = np.random.RandomState(0).random_sample((n, n, n)).astype(np.float32)
+if n >= 768:                                   # generate on the device: 4 GiB of host random numbers is most of a short run
+    import torch
+    vol = torch.rand((n, n, n), dtype=torch.float32, device='cuda:0')
+else:
+    vol = np.random.RandomState(0).random_sample((n, n, n)).astype(np.float32)
 sv = vt.StaticVolume(vol, interpolation=args.interp, device='gpu:0')
 out = vt.empty((n, n, n), device='gpu:0')
 c = np.divide(np.subtract((n, n, n), 1), 2, dtype=np.float32)

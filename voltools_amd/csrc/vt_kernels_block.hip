@@ -158,6 +158,49 @@ __global__ __launch_bounds__(256, 2) void affine_block(const float* __restrict__
     const int ostep_d = (int)(4 * ostride * 4), ostep_h = (int)(8 * (int64_t)p.oW * 4);
     const unsigned ps4 = 4u * (unsigned)ps;
     const unsigned lds_base = lds_byte_address(lds);
+    // The step increments live in vector registers (there are plenty at 2 workgroups per CU): as scalars they are 30 of ~150 live
+    // SGPR values of the tile loop, and the spilled ones come back through v_readlane at every use.
+    int inc_hi[5][3];
+    unsigned inc_lo[5][3];
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            inc_hi[k][r] = p.binc_hi[k][r];
+            inc_lo[k][r] = p.binc_lo[k][r];
+            asm volatile("" : "+v"(inc_hi[k][r]), "+v"(inc_lo[k][r]));
+        }
+    // ... and so do the float64 constants of the tile geometry (float64 arithmetic is vector arithmetic anyway)
+    double gm[12], gneg[3], gpos[3], gvlo[3], gvhi[3];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { gm[i] = p.m[i]; asm volatile("" : "+v"(gm[i])); }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        gneg[r] = p.neg[r]; gpos[r] = p.pos[r]; gvlo[r] = p.vlo[r]; gvhi[r] = p.vhi[r];
+        asm volatile("" : "+v"(gneg[r]), "+v"(gpos[r]), "+v"(gvlo[r]), "+v"(gvhi[r]));
+    }
+    // canonical_inside (vt_device.h) on the register copies of the matrix: the same float64 chain in the original problem's column order
+    const int oc0 = p.ord[0], oc1 = p.ord[1], oc2 = p.ord[2];
+    double mp[3][3];                                              // matrix columns in the chain's order
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        mp[r][0] = oc0 == 0 ? p.m[4 * r] : (oc0 == 1 ? p.m[4 * r + 1] : p.m[4 * r + 2]);
+        mp[r][1] = oc1 == 0 ? p.m[4 * r] : (oc1 == 1 ? p.m[4 * r + 1] : p.m[4 * r + 2]);
+        mp[r][2] = oc2 == 0 ? p.m[4 * r] : (oc2 == 1 ? p.m[4 * r + 1] : p.m[4 * r + 2]);
+        asm volatile("" : "+v"(mp[r][0]), "+v"(mp[r][1]), "+v"(mp[r][2]));
+    }
+    auto inside_canonical = [&](int d, int h, int w) {
+        const double x0 = (double)(oc0 == 0 ? d : (oc0 == 1 ? h : w));
+        const double x1 = (double)(oc1 == 0 ? d : (oc1 == 1 ? h : w));
+        const double x2 = (double)(oc2 == 0 ? d : (oc2 == 1 ? h : w));
+        bool in = true;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const double sc = fma(mp[r][0], x0, fma(mp[r][1], x1, fma(mp[r][2], x2, gm[4 * r + 3])));
+            in = in && (sc >= gvlo[r]) && (sc < gvhi[r]);
+        }
+        return in;
+    };
 #ifdef VT_EXPERIMENTS      // make EXTRA=-DVT_EXPERIMENTS: VT_EXP_NOSTORE / VT_EXP_NOLOAD / VT_EXP_NOLDS ablations
     const bool no_stores = (p.flags & (1 << 21)) != 0, no_loads = (p.flags & (1 << 22)) != 0, no_lds = (p.flags & (1 << 26)) != 0;
 #else
@@ -202,11 +245,11 @@ __global__ __launch_bounds__(256, 2) void affine_block(const float* __restrict__
         bool any_valid = true, all_valid = true;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            base[r] = fma(p.m[4 * r], (double)d0, fma(p.m[4 * r + 1], (double)h0, fma(p.m[4 * r + 2], (double)w0, p.m[4 * r + 3])));
-            lo[r] = base[r] + p.neg[r];
-            hi[r] = base[r] + p.pos[r];
-            any_valid = any_valid && (hi[r] >= p.vlo[r] - kTileMargin) && (lo[r] < p.vhi[r] + kTileMargin);
-            all_valid = all_valid && (lo[r] >= p.vlo[r] + kTileMargin) && (hi[r] < p.vhi[r] - kTileMargin);
+            base[r] = fma(gm[4 * r], (double)d0, fma(gm[4 * r + 1], (double)h0, fma(gm[4 * r + 2], (double)w0, gm[4 * r + 3])));
+            lo[r] = base[r] + gneg[r];
+            hi[r] = base[r] + gpos[r];
+            any_valid = any_valid && (hi[r] >= gvlo[r] - kTileMargin) && (lo[r] < gvhi[r] + kTileMargin);
+            all_valid = all_valid && (lo[r] >= gvlo[r] + kTileMargin) && (hi[r] < gvhi[r] - kTileMargin);
         }
         float* const otile = out + ((int64_t)d0 * ostride + (int64_t)h0 * p.oW + w0);
         __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(otile), 0, 0x7fffffff, 0x00020000);
@@ -248,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void affine_block(const float* __restrict__
         Fx c[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r)
-            c[r] = to_fx(fma(p.m[4 * r], (double)vd, fma(p.m[4 * r + 1], (double)vh, fma(p.m[4 * r + 2], (double)vw, base[r] - (double)o[r]))));
+            c[r] = to_fx(fma(gm[4 * r], (double)vd, fma(gm[4 * r + 1], (double)vh, fma(gm[4 * r + 2], (double)vw, base[r] - (double)o[r]))));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
@@ -286,14 +329,14 @@ __global__ __launch_bounds__(256, 2) void affine_block(const float* __restrict__
                 // tiles cut by the skirt or by the end of the output: the inside test is the canonical float64 chain
                 const int d = d0 + vd + sd[s], h = h0 + vh + sh[s], w = w0 + vw + sw[s];
                 if (d < p.oD && h < p.oH && w < p.oW) {
-                    const bool inside = canonical_inside(p, d, h, w);
+                    const bool inside = inside_canonical(d, h, w);
                     if (inside) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), orsrc, obase, soff, 0);
                     else if (!keep) __builtin_amdgcn_raw_buffer_store_b32(0u, orsrc, obase, soff, 0);
                 }
             }
             if (s < 7) {
 #pragma unroll
-                for (int r = 0; r < 3; ++r) fx_step(c[r], p.binc_hi[which[s]][r], p.binc_lo[which[s]][r]);
+                for (int r = 0; r < 3; ++r) fx_step(c[r], inc_hi[which[s]][r], inc_lo[which[s]][r]);
             }
             // (no scheduling barrier: at 2 waves per SIMD the compiler may overlap the next voxel's weights with this one's taps)
         }

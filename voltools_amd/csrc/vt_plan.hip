@@ -797,9 +797,10 @@ bool plan_block(PlanCtx& c)
     // trilinear: staging dominates (8 taps per voxel against 25 staged bytes), and the packed-footprint kernel stages a third of a
     // box: [measured] 512^3 general rotation 0.78 ms here, 0.52 ms packed.  VT_BLOCK_LINEAR=1 keeps the path testable.
     if (!c.cubic && !v->tune.block_linear) return false;
-    // persistent workgroups want many tiles each: [measured, 100 random rotations] 128^3 0.056 vs 0.030 ms on boxes, 250^3 0.179 vs
-    // 0.162, 384^3 0.507 vs 0.557, 512^3 1.14 vs 1.24 (tools/general_ab.py)
-    if (!(c.flags & VT_FORCE_TILED) && (int64_t)v->oD * v->oH * v->oW < (int64_t)320 * 320 * 320) return false;
+    // persistent workgroups want many tiles each: [measured, 100 random rotations, ms, lane blocks vs boxes] 160^3 0.071 / 0.050,
+    // 200^3 0.112 / 0.090, 250^3 0.158 / 0.161, 288^3 0.212 / 0.223, 384^3 0.473 / 0.553, 512^3 1.05 / 1.23, 640^3 2.10 / 2.62
+    // (tools/general_ab.py, VT_BLOCK_MIN)
+    if (!(c.flags & VT_FORCE_TILED) && (int64_t)v->oD * v->oH * v->oW < (int64_t)v->tune.block_min * v->tune.block_min * v->tune.block_min) return false;
     int T[3];
     block_tile(&T[0], &T[1], &T[2]);
     int L[3];
