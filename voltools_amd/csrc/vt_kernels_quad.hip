@@ -277,9 +277,11 @@ __global__ __launch_bounds__(NT) void affine_march4(const float* __restrict__ sr
                 // not fit the slot, the unpadded prefix sum above stays.
                 int pos = 0, first_p = 0, pad_p = 0;
                 const int S = p.row_s;
-                for (int r = 0; r < kRowsMax; ++r) {
+                unsigned long long todo = __ballot(nv > 0);       // rows in use (a third to a half of the 64): visit only those
+                while (todo) {
+                    const int r = __builtin_ctzll(todo);
+                    todo &= todo - 1;
                     const int nv_r = __builtin_amdgcn_readlane(nv, r);
-                    if (nv_r == 0) continue;
                     const int x0_r = __builtin_amdgcn_readlane(x0, r);
                     const int gap = (x0_r + r * S - pos) & 15;
                     pos += gap;
