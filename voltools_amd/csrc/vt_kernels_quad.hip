@@ -131,6 +131,9 @@ __global__ __launch_bounds__(NT) void affine_march4(const float* __restrict__ sr
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x;
+#ifdef VT_EXPERIMENTS      // VT_EXP_NOLOOP + VT_EXP_NOLDS: the launch alone (workgroup dispatch, LDS allocation, argument loads)
+    if ((p.flags & (1 << 27)) && (p.flags & (1 << 26))) return;
+#endif
     int tw_i, th_i, chunk;
     if (p.flags & (1 << 29)) {
         // 2-D grid: blockIdx.y = chunk, blockIdx.x = in-plane tile.  Workgroups are dispatched x-fastest, so each XCD gets a
@@ -295,7 +298,12 @@ __global__ __launch_bounds__(NT) void affine_march4(const float* __restrict__ sr
             if (lane == 0) tab[2 * kRowsMax] = total;
             const int last = min(first + nv, kVrowCap);
             for (int v = max(first - pad, 0); v < min(first, kVrowCap); ++v) vrow[v] = 255;
-            for (int v = first; v < last; ++v) vrow[v] = (unsigned char)lane;
+            // a row's run of entries: bytes up to the next word, whole words, bytes (runs of different lanes share words only at their ends)
+            int v = first;
+            for (; v < last && (v & 3); ++v) vrow[v] = (unsigned char)lane;
+            const unsigned lane4 = (unsigned)lane * 0x01010101u;
+            for (; v + 4 <= last; v += 4) *reinterpret_cast<unsigned*>(vrow + v) = lane4;
+            for (; v < last; ++v) vrow[v] = (unsigned char)lane;
         }
         __syncthreads();
 #endif
