@@ -215,6 +215,7 @@ __global__ __launch_bounds__(256, 2) void affine_block(const float* __restrict__
     // The id of the next tile is fetched while the current one is gathered.  The last workgroup to leave zeroes the counters.
     int* const ctrl = reinterpret_cast<int*>(lds + (p.lds_cap >> 2));      // one word behind the box
     const int nids = blocked_tile_count(p.nTd, p.nTh, p.nTw);
+    const int nSh = (p.nTh + 3) >> 2, nSw = (p.nTw + 3) >> 2;
     const int xcd = blockIdx.x & 7, per = ((nids >> 6) + 7) / 8 * 64;      // whole super-blocks per XCD
     const int id0 = xcd * per, id_cnt = max(0, min(per, nids - id0));
     // one counter per XCD, each on a cache line of its own; a fetch hands out kBlkChunk consecutive ids
@@ -236,7 +237,13 @@ __global__ __launch_bounds__(256, 2) void affine_block(const float* __restrict__
         ++cur; --left;
         if (cur > id_cnt) continue;
         int td_i, th_i, tw_i;
-        const bool tile_ok = blocked_tile(id, p.nTd, p.nTh, p.nTw, td_i, th_i, tw_i);
+        // blocked_tile (vt_device.h) with the two divisions as multiply-high by host constants (p.nTw_magic / p.nTh_magic hold the
+        // magic numbers of the super-block counts along w / h here): the tile decode was half of the loop's uniform arithmetic
+        const unsigned sbi = (unsigned)id >> 6, l6 = (unsigned)id & 63u;
+        const unsigned s2 = nSw == 1 ? sbi : __umulhi(sbi, p.nTw_magic), sbw = sbi - s2 * (unsigned)nSw;      // (a count of 1 has no 32-bit magic number)
+        const unsigned sbd = nSh == 1 ? s2 : __umulhi(s2, p.nTh_magic), sbh = s2 - sbd * (unsigned)nSh;
+        td_i = (int)(sbd * 4 + (l6 >> 4)); th_i = (int)(sbh * 4 + ((l6 >> 2) & 3)); tw_i = (int)(sbw * 4 + (l6 & 3));
+        const bool tile_ok = td_i < p.nTd && th_i < p.nTh && tw_i < p.nTw;
         if (!tile_ok) continue;
         const int d0 = td_i * TD, h0 = th_i * TH, w0 = tw_i * TW;
 

@@ -844,6 +844,9 @@ bool plan_block(PlanCtx& c)
     p->nTw = (v->oW + T[2] - 1) / T[2];
     p->psv_magic = (uint32_t)(4294967296.0 / (double)(PS / 4)) + 1u;
     p->lds_cap = box_bytes;
+    // the kernel's tile decode divides super-block indices by the super-block counts along w and h: (u * magic) >> 32 == u / n
+    p->nTw_magic = (uint32_t)((1ULL << 32) / (uint64_t)((p->nTw + 3) >> 2) + 1);
+    p->nTh_magic = (uint32_t)((1ULL << 32) / (uint64_t)((p->nTh + 3) >> 2) + 1);
     // steps between a thread's eight voxels (Gray order): +8 w, +8 h, -8 w, +4 d, -8 h; a backward step is the exact negative of
     // the forward one, so that the walk closes
     const int col[5] = {2, 1, 2, 0, 1};
