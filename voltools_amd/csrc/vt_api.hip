@@ -555,7 +555,7 @@ int launch_planned(vt_volume* v, const TilePlan& plan, const AffineParams& p, co
             VT_HIP(hipMalloc(reinterpret_cast<void**>(&v->d_queue), 9 * 128));
             VT_HIP(hipMemsetAsync(v->d_queue, 0, 9 * 128, v->stream));
         }
-        VT_HIP(launch_affine_block(plan.cfg, v->interp, v->d_src, d_out, v->d_zeros, v->d_queue, p, plan.grid, plan.lds_bytes, v->stream));
+        VT_HIP(launch_affine_block(plan.cfg, v->interp, v->d_src, d_out, v->d_zeros, v->d_queue, p, plan.geo, plan.grid, plan.lds_bytes, v->stream));
     } else if (plan.kind == 6) {
         VT_HIP(launch_affine_packed(plan.cfg, v->interp, v->d_src, d_out, v->d_zeros, p, plan.geo, plan.grid, plan.lds_bytes, v->stream));
     } else if (plan.kind == 4) {

@@ -27,6 +27,7 @@ struct Tuning {
     bool no_block = false;         // VT_NO_BLOCK_KERNEL: general matrices on the round-1 box / packed kernels
     int block_rs = -1;             // VT_BLOCK_RS: force the row-stride index of the lane-block kernel (if it holds the box)
     bool block_linear = false;     // VT_BLOCK_LINEAR: trilinear general matrices on the lane-block kernel too (slower than packed footprints)
+    bool block_no_trim = false;    // VT_BLOCK_NO_TRIM: the lane-block kernel stages whole boxes (A/B of the footprint trimming)
     int block_min = 256;           // VT_BLOCK_MIN: smallest output (cube edge) that general cubic launches take to the lane-block kernel
     int block_pad = -1;            // VT_BLOCK_PAD: plane-stride padding in floats instead of the bank model's choice
     void read()
@@ -54,6 +55,7 @@ struct Tuning {
         block_linear = std::getenv("VT_BLOCK_LINEAR") != nullptr;
         block_pad = num("VT_BLOCK_PAD", -1);
         block_min = std::max(1, num("VT_BLOCK_MIN", 256));
+        block_no_trim = std::getenv("VT_BLOCK_NO_TRIM") != nullptr;
     }
 };
 

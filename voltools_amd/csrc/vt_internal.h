@@ -226,7 +226,7 @@ int block_max_vectors();
 void block_tile(int* td, int* th, int* tw);
 hipError_t init_block_kernels();
 hipError_t launch_affine_block(int rs_idx, int interp, const float* src, float* out, const float* zeros16, int* queue,
-                               const AffineParams& p, int grid, int lds_bytes, hipStream_t stream);
+                               const AffineParams& p, const PackGeom& geo, int grid, int lds_bytes, hipStream_t stream);
 int packed_config_count();
 void packed_config(int idx, int* td, int* th, int* tw);
 int packed_rows_max();

@@ -117,7 +117,8 @@ __device__ __forceinline__ void stage_block_checked(float* lds, const float* __r
 
 template <int KIND, int RS>
 __global__ __launch_bounds__(256, 2) void affine_block(const float* __restrict__ src, float* __restrict__ out,
-                                                        const float* __restrict__ zeros16, int* __restrict__ queue, const AffineParams p)
+                                                        const float* __restrict__ zeros16, int* __restrict__ queue, const AffineParams p,
+                                                        const PackGeom geo)
 {
     constexpr bool CUBIC = KIND != 0;
     constexpr int HALO = CUBIC ? 1 : 0;
@@ -149,7 +150,17 @@ __global__ __launch_bounds__(256, 2) void affine_block(const float* __restrict__
         const int v = k * 256 + tid;
         const int z = (int)__umulhi((unsigned)v, p.psv_magic), rem = v - z * psv;      // v / psv (v * psv < 2^32)
         const int y = rem / nvx, cx = rem - y * nvx;
-        voff[k] = (v < total && y < Ly && cx < nvx_used) ? z * plane_b + y * row_b + 16 * cx : 0;
+        bool used = v < total && y < Ly && cx < nvx_used;
+        if (used && (p.flags & (1 << 25))) {
+            // Footprint trimming: of row (z, y) of the box only the columns some tile voxel can reach are staged -- the span that
+            // packed_row_span (vt_internal.h) proves for EVERY sub-voxel position of a tile, widened by the column on either side
+            // that the aligned 6-wide window of the cubic gather may read with weight 0.  The LDS image keeps the box's strides, so
+            // the gather is unchanged; unstaged slots keep whatever an earlier tile left there and are never read.
+            int mn, mx;
+            used = packed_row_span(geo, z, y, &mn, &mx);
+            used = used && cx >= ((max(mn - HALO, 0)) >> 2) && cx <= ((mx + HALO) >> 2);
+        }
+        voff[k] = used ? z * plane_b + y * row_b + 16 * cx : 0;
     }
 
     const bool keep = (p.flags & VT_KEEP_OUTSIDE) != 0;
@@ -360,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void affine_block(const float* __restrict__
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
-typedef void (*block_fn)(const float*, float*, const float*, int*, const AffineParams);
+typedef void (*block_fn)(const float*, float*, const float*, int*, const AffineParams, const PackGeom);
 
 static const int kBlkRS[] = {28, 36};
 int block_rs_count() { return (int)(sizeof(kBlkRS) / sizeof(kBlkRS[0])); }
@@ -392,9 +403,9 @@ hipError_t init_block_kernels()
 }
 
 hipError_t launch_affine_block(int rs_idx, int interp, const float* src, float* out, const float* zeros16, int* queue,
-                               const AffineParams& p, int grid, int lds_bytes, hipStream_t stream)
+                               const AffineParams& p, const PackGeom& geo, int grid, int lds_bytes, hipStream_t stream)
 {
-    hipLaunchKernelGGL(block_entry(rs_idx, interp_kind(interp)), dim3(grid), dim3(256), lds_bytes, stream, src, out, zeros16, queue, p);
+    hipLaunchKernelGGL(block_entry(rs_idx, interp_kind(interp)), dim3(grid), dim3(256), lds_bytes, stream, src, out, zeros16, queue, p, geo);
     return hipGetLastError();
 }
 

@@ -839,6 +839,21 @@ bool plan_block(PlanCtx& c)
     p->Lz = L[0]; p->Ly = L[1]; p->Lx = RS; p->Lx_used = lx_used; p->Lps = PS;
     p->flags = (c.flags & VT_KEEP_OUTSIDE) | experiment_flags(v);
     set_tile_reach(p, m, T, 0);
+    // footprint trimming (invertible linear part): the kernel stages, per box row, only the columns packed_row_span proves reachable
+    double inv[9];
+    if (!v->tune.block_no_trim && invert3(m, inv)) {
+        PackGeom& g = plan->geo;
+        for (int i = 0; i < 9; ++i) g.inv[i] = inv[i];
+        for (int cc = 0; cc < 3; ++cc) g.cst[cc] = inv[3 * cc] * p->neg[0] + inv[3 * cc + 1] * p->neg[1] + inv[3 * cc + 2] * p->neg[2];
+        for (int r = 0; r < 3; ++r) {
+            g.ext[r] = p->pos[r] - p->neg[r];
+            g.T[r] = T[r];
+        }
+        g.halo = c.cubic ? 1 : 0;
+        g.Lxbox = lx_used;
+        g.Lybox = L[1];
+        p->flags |= (1 << 25);
+    }
     p->nTd = (v->oD + T[0] - 1) / T[0];
     p->nTh = (v->oH + T[1] - 1) / T[1];
     p->nTw = (v->oW + T[2] - 1) / T[2];
