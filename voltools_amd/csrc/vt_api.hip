@@ -513,7 +513,12 @@ int try_inplane_transposed(vt_volume* v, const double m[12], int flags, size_t n
     *p = ps; *plan = plans;
     ori->src_plain = v->d_src_r; ori->pair_slot = &v->d_src_r_zp; ori->quad_slot = &v->d_src_r_q; ori->quad_idx = 2;
     ori->srcD = v->D; ori->srcH = v->W; ori->pair_W = v->H; ori->pair_P = v->Pr;
-    if (!v->tune.rswap_wfast) p->flags |= (1 << 24);          // h-fastest tile order on the transposed copy
+    // Tile order on the transposed copy: h fastest for the round-1 marching kernels (consecutive tiles read neighbouring source
+    // rows); the plane-quad kernel with its 2-D grid keeps w fastest -- [measured, angles 50..130] 1024^3 trilinear 1.58-1.70 ->
+    // 1.51-1.63 ms, 1024^3 cubic at 80 / 90 degrees 1.76 / 1.79 -> 1.65 / 1.61, 512^3 equal or better (consecutive tiles complete whole
+    // output rows instead of writing down a column of tiles).  VT_RSWAP_WFAST=1 / 0 forces either.
+    const bool wfast = v->tune.rswap_wfast >= 0 ? v->tune.rswap_wfast != 0 : plans.kind == 8;
+    if (!wfast) p->flags |= (1 << 24);
     return 0;
 }
 

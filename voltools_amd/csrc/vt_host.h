@@ -16,7 +16,7 @@ struct Tuning {
     int dch = 0;                   // VT_DCH: output planes per marching chunk
     int blk_h = -1, blk_w = -1;    // VT_BLK_H / VT_BLK_W: blocked tile order of the marching kernels (tiles per block; 0 = plain order)
     bool plain_tile_order = false; // VT_TILE_ORDER=0: packed kernel walks tiles in plain instead of blocked order
-    bool rswap_wfast = false;      // VT_RSWAP_WFAST: keep the w-fastest tile order on the in-plane transposed copy
+    int rswap_wfast = -1;          // VT_RSWAP_WFAST: 1 / 0 = w-fastest / h-fastest tile order on the in-plane transposed copy, -1 = by kernel
     bool exp_nostore = false;      // VT_EXP_NOSTORE / VT_EXP_NOLOAD / VT_EXP_NOLDS: ablation builds (-DVT_EXPERIMENTS) only
     bool exp_noload = false;
     bool exp_nolds = false;
@@ -42,7 +42,7 @@ struct Tuning {
         blk_h = num("VT_BLK_H", -1);
         blk_w = num("VT_BLK_W", -1);
         plain_tile_order = num("VT_TILE_ORDER", 1) == 0;
-        rswap_wfast = std::getenv("VT_RSWAP_WFAST") != nullptr;
+        rswap_wfast = num("VT_RSWAP_WFAST", -1);
         exp_nostore = std::getenv("VT_EXP_NOSTORE") != nullptr;
         exp_noload = std::getenv("VT_EXP_NOLOAD") != nullptr;
         exp_nolds = std::getenv("VT_EXP_NOLDS") != nullptr;
