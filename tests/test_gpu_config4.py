@@ -17,7 +17,7 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 
 N = 1024
-TOL = {'linear': 2e-6, 'filt_bspline': 1e-5}
+TOL = {'linear': 1e-6, 'filt_bspline': 3e-6}
 
 
 def centre(shape):

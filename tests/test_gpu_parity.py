@@ -17,7 +17,7 @@ from conftest import interior_mask
 
 pytestmark = pytest.mark.gpu
 
-TOL = {'linear': 2e-6, 'bspline': 2e-6, 'bspline_simple': 2e-6, 'filt_bspline': 1e-5, 'filt_bspline_simple': 1e-5}
+TOL = {'linear': 1e-6, 'bspline': 1e-6, 'bspline_simple': 1e-6, 'filt_bspline': 3e-6, 'filt_bspline_simple': 3e-6}
 ALL_INTERPS = list(TOL)
 
 
