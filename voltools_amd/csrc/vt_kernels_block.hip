@@ -34,7 +34,6 @@ namespace vt {
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 constexpr int kBlkTD = 8, kBlkTH = 16, kBlkTW = 16;
-constexpr int kBlkChunk = 4;                  // tile ids per queue fetch
 constexpr int kBlkMaxIt = 20;                 // staging vectors per thread: boxes up to 5120 vectors = 80 KiB
 
 template <int OFF>
@@ -229,20 +228,21 @@ __global__ __launch_bounds__(256, 2) void affine_block(const float* __restrict__
     const int nSh = (p.nTh + 3) >> 2, nSw = (p.nTw + 3) >> 2;
     const int xcd = blockIdx.x & 7, per = ((nids >> 6) + 7) / 8 * 64;      // whole super-blocks per XCD
     const int id0 = xcd * per, id_cnt = max(0, min(per, nids - id0));
-    // one counter per XCD, each on a cache line of its own; a fetch hands out kBlkChunk consecutive ids
+    // one counter per XCD, each on a cache line of its own; a fetch hands out `chunk` consecutive ids
     int* const counter = queue + 32 * xcd;
+    const int chunk = p.dch;                                     // ids per fetch: 4 on large grids, fewer where a workgroup serves only a few tiles
     int nxt = 0;
-    if (tid == 0) nxt = atomicAdd(counter, kBlkChunk);
+    if (tid == 0) nxt = atomicAdd(counter, chunk);
     int cur = 0, left = 0;
     for (;;) {
         if (left == 0) {
             if (tid == 0) ctrl[0] = nxt;
             __syncthreads();                                     // the next chunk is visible
             cur = ctrl[0];
-            left = kBlkChunk;
+            left = chunk;
             __syncthreads();                                     // everyone has read it before thread 0 may overwrite it
             if (cur >= id_cnt) break;
-            if (tid == 0) nxt = atomicAdd(counter, kBlkChunk);
+            if (tid == 0) nxt = atomicAdd(counter, chunk);
         }
         const int id = id0 + cur;
         ++cur; --left;

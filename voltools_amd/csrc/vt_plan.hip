@@ -886,6 +886,8 @@ bool plan_block(PlanCtx& c)
     const int64_t ids = blocked_tile_count(p->nTd, p->nTh, p->nTw);
     int64_t grid = std::min<int64_t>((int64_t)v->cu_count * plan->blocks_per_cu, ids);
     grid = std::max<int64_t>(8, (grid + 7) / 8 * 8);              // persistent workgroups, the same number on every XCD
+    // ids per queue fetch: 4 where every workgroup serves many tiles, 1 on small grids (a chunk of 4 would leave workgroups idle)
+    p->dch = (int)std::max<int64_t>(1, std::min<int64_t>(4, ids / (grid * 8)));
     plan->grid = (int)grid;
     return true;
 }
