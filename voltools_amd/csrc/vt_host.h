@@ -23,6 +23,7 @@ struct Tuning {
     bool exp_noloop = false;
     int quad_rows = -2;            // VT_QUAD_ROWS: -1 = rows packed back to back, 0..15 = force the row stride S of the bank-aware placement, -2 = planner
     int quad_grid2d = 1;           // VT_QUAD_GRID2D=0: 1-D grid with XCD-contiguous ids over all chunks (round-2 A/B)
+    int quad_reverse = -1;         // VT_QUAD_REVERSE: 1 / 0 = the 2-D grid walks the in-plane tiles in descending / ascending order, -1 = planner
     int quad_nt = -1;              // VT_QUAD_NT: 1 / 0 = nontemporal / plain output stores of the plane-quad kernel, -1 = planner's choice
     bool no_block = false;         // VT_NO_BLOCK_KERNEL: general matrices on the round-1 box / packed kernels
     int block_rs = -1;             // VT_BLOCK_RS: force the row-stride index of the lane-block kernel (if it holds the box)
@@ -48,6 +49,7 @@ struct Tuning {
         exp_nolds = std::getenv("VT_EXP_NOLDS") != nullptr;
         exp_noloop = std::getenv("VT_EXP_NOLOOP") != nullptr;
         quad_nt = num("VT_QUAD_NT", -1);
+        quad_reverse = num("VT_QUAD_REVERSE", -1);
         quad_grid2d = num("VT_QUAD_GRID2D", 1);
         quad_rows = num("VT_QUAD_ROWS", -2);
         no_block = std::getenv("VT_NO_BLOCK_KERNEL") != nullptr;

@@ -140,7 +140,8 @@ __global__ __launch_bounds__(NT) void affine_march4(const float* __restrict__ sr
         // contiguous band of every chunk layer in turn: the chip works on one or two layers at a time (compact write stream,
         // halos shared inside the band), and the tile decode needs one multiply-high instead of two integer divisions.
         chunk = blockIdx.y;
-        const unsigned u = (unsigned)xcd_contiguous(blockIdx.x, gridDim.x);
+        unsigned u = (unsigned)xcd_contiguous(blockIdx.x, gridDim.x);
+        if (p.flags & (1 << 30)) u = gridDim.x - 1 - u;             // A/B: tiles walked in descending order
         if (p.flags & (1 << 24)) {                // h fastest (in-plane transposed copy)
             tw_i = (int)__umulhi(u, p.nTh_magic);
             th_i = (int)u - tw_i * p.nTh;

@@ -359,6 +359,9 @@ bool plan_quad(PlanCtx& c)
         p->nTw_magic = (uint32_t)((1ULL << 32) / (uint64_t)p->nTw + 1);
         p->nTh_magic = (uint32_t)((1ULL << 32) / (uint64_t)p->nTh + 1);
         p->flags |= (1 << 29);
+        // descending tile order when the source rows run backwards as the tile row advances (m[1][1] < 0 on the launch's matrix)
+        const bool rev = v->tune.quad_reverse >= 0 ? v->tune.quad_reverse != 0 : c.m[5] < 0.0;
+        if (rev) p->flags |= (1 << 30);
     }
     return true;
 }
