@@ -64,16 +64,18 @@ def cpu_baseline(vol, interp, matrices, target_s):
     res = {'value': round(done / dt / 1e6, 2), 'unit': 'Mvoxels/s', 'cores': threads, 'kind': 'port',
            'sample': f'{k} sweep angles x {planes} of {n} output planes of the same {n}^3 {interp} transform (prefilter not '
                      f'timed), oracle/vt_oracle.c with {threads} OpenMP threads, {dt:.1f} s of CPU work'}
-    # the reference's actual CPU path (scipy, single-threaded) on BASELINE config #1's size
+    # the reference's actual CPU path (scipy, single-threaded) on BASELINE config #1's size: config #1 itself (200^3 'linear',
+    # 45 deg rzxz) and the same volume with the headline interpolation
     try:
         import voltools_amd as vt
         small = np.random.RandomState(0).random_sample((200, 200, 200)).astype(np.float32)
-        t0 = time.perf_counter()
-        vt.transform(small, rotation=(0, 45, 0), interpolation=interp, device='cpu')
-        dt = time.perf_counter() - t0
-        res['scipy_1thread'] = {'value': round(200 ** 3 / dt / 1e6, 2), 'unit': 'Mvoxels/s', 'cores': 1,
-                                'sample': f'200^3 {interp} via voltools_amd device="cpu" (scipy.ndimage.affine_transform, the '
-                                          f'reference CPU path), {dt:.1f} s'}
+        for key, ip in (('scipy_1thread_config1', 'linear'), ('scipy_1thread', interp)):
+            t0 = time.perf_counter()
+            vt.transform(small, rotation=(0, 45, 0), rotation_units='deg', rotation_order='rzxz', interpolation=ip, device='cpu')
+            dt = time.perf_counter() - t0
+            res[key] = {'value': round(200 ** 3 / dt / 1e6, 2), 'unit': 'Mvoxels/s', 'cores': 1,
+                        'sample': f'200^3 {ip}, 45 deg rzxz, via voltools_amd device="cpu" (scipy.ndimage.affine_transform, the '
+                                  f'reference CPU path' + (', BASELINE config #1' if ip == 'linear' else '') + f'), {dt:.2f} s'}
     except Exception as e:  # pragma: no cover
         res['scipy_1thread'] = {'error': str(e)}
     return res
@@ -210,12 +212,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # per-step distribution (after the timed region, one event pair per launch): the sweep's angles differ by +-10 %
+    # per-angle distribution (after the timed region): the sweep's angles differ by +-10 % (footprint shape).  One event pair
+    # brackets `rep` back-to-back launches of the SAME angle, so the event pair's own cost and the launch gap (~17 us together,
+    # 8 % of a 0.2 ms launch: round 2's single-launch samples read above the mean of the timed region) are amortised.
+    rep = 8
     step_ms = []
     for i in range(min(args.steps, 180)):
         sv.timer_start()
-        sv.affine(mats[args.warmup + i], output=out)
-        step_ms.append(sv.timer_stop())
+        for _ in range(rep):
+            sv.affine(mats[args.warmup + i], output=out)
+        step_ms.append(sv.timer_stop() / rep)
     step_ms = np.asarray(step_ms)
 
     info = sv.info()
@@ -243,9 +249,20 @@ def main():
                      'traffic': (round(traffic['bytes']) if traffic else None),
                      'traffic_source': (traffic['source'] if traffic else None),
                      'counters': (traffic['extra'] if traffic else None),
-                     'kernel_ms': round(kernel_ms, 4), 'kernel_ms_min': round(float(step_ms.min()), 4),
-                     'kernel_ms_median': round(float(np.median(step_ms)), 4), 'algorithmic_bytes_per_launch': algo_bytes},
+                     'kernel_ms': round(kernel_ms, 4), 'algorithmic_bytes_per_launch': algo_bytes,
+                     'per_angle_ms': {'min': round(float(step_ms.min()), 4), 'median': round(float(np.median(step_ms)), 4),
+                                      'max': round(float(step_ms.max()), 4), 'mean': round(float(step_ms.mean()), 4),
+                                      'method': f'{rep} back-to-back launches of one angle per HIP event pair, after the timed region'}},
     }
+    if use_slab:
+        # the path's only communication happened once, at construction (halo planes, point to point)
+        hm = torch.tensor([float(sv.halo_ms)], dtype=torch.float64, device='cuda')
+        if world > 1:
+            dist.all_reduce(hm, op=dist.ReduceOp.MAX)
+        result['halo_exchange'] = {'halo_ms': round(float(hm.item()), 3), 'exchanged_bytes': int(sv.exchanged_bytes),
+                                   'sent_bytes': int(sv.sent_bytes), 'window_planes': [int(sv.window[0]), int(sv.window[1])],
+                                   'halo_planes': int(sv.halo), 'when': 'once, at SlabVolume construction (rank 0\'s bytes; max over ranks ms)',
+                                   'backend': 'gloo (BENCH_ONE_GPU rehearsal)' if one_gpu else 'nccl (RCCL)'}
 
     if rank == 0 and world == 1:
         # extra (not the headline): the linear kernel on the same volume, and the prefilter's own roofline

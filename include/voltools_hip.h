@@ -87,7 +87,7 @@ typedef struct vt_volume vt_volume_t;
 typedef struct vt_volume_info {
     int32_t device;
     int32_t interp;
-    int32_t depth, height, width;      /* resident source dims (including any slab halo planes)            */
+    int32_t depth, height, width;      /* source dims as passed to create (including any slab halo planes; the mirror padding of VT_EDGE_SCIPY handles is not counted) */
     int32_t out_depth, out_height, out_width;
     int32_t last_kernel;               /* 0 none, 1 direct, 2 tiled (boxes), 3 tiled axis-0-separable, 4 marching, 5 marching on plane pairs, 6 tiled (packed footprints), 7 fused projection, 8 marching on plane quads, 9 lane-block tiles (general matrices) */
     int32_t last_tile[3];              /* output tile (TD, TH, TW) of the last tiled launch (marching: G, TH, TW) */

@@ -626,7 +626,7 @@ def test_slab_handles_reproduce_whole_volume(interp):
     mats = [vt.utils.transform_matrix(rotation=(0, 33, 0), translation=(0.0, 1.5, -2.0), center=c),
             vt.utils.transform_matrix(rotation=(0, 45, 0), translation=(1.25, 0, 0), center=c)]
     halo = stencil_halo(interp) + 2
-    tol = TOL[interp] if not interp.startswith('filt') else 2e-5
+    tol = TOL[interp]        # filt_*: the window carries 16 warm-up planes (|z|^16 = 7e-10): same bar as a whole resident volume
     for m in mats:
         want = oracle.affine(vol, m, interp)
         projs = {}

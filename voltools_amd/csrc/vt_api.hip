@@ -532,28 +532,54 @@ void note_launch(vt_volume* v, int kind, const TilePlan& plan, const AffineParam
     v->last_grid = tiled ? plan.grid : (int)((n_out + 255) / 256);
 }
 
-// build the secondary resident copy a plan needs (once), then launch the plan's kernel into d_out
+// Build the secondary resident copy a plan needs (once per handle and orientation).  Returns 0 when the copy exists, 1 when it
+// could not be built -- no device memory for it, or a relayout launch that was refused: the slot is freed and cleared (a zero-filled
+// copy must never survive: later calls would sample it silently) and the caller re-plans without this kernel family --, < 0 never.
+int ensure_secondary_copy(vt_volume* v, const TilePlan& plan, const AffineParams& p, const Orientation& ori)
+{
+    float** slot = nullptr;
+    size_t bytes = 0;
+    if (plan.kind == 8) {
+        slot = ori.quad_slot;
+        bytes = (size_t)((ori.srcD + 3) / 4) * ori.srcH * p.sPq * sizeof(float);
+    } else if (plan.kind == 5) {
+        slot = ori.pair_slot;
+        bytes = (size_t)((ori.srcD + 1) / 2) * ori.srcH * p.sP2 * sizeof(float);
+    } else return 0;
+    if (*slot) return 0;
+    if (hipMalloc(reinterpret_cast<void**>(slot), bytes) != hipSuccess) {
+        (void)hipGetLastError();              // no room for another copy of the volume: a family that reads the plain layout serves the call
+        *slot = nullptr;
+        return 1;
+    }
+    hipError_t e = hipMemsetAsync(*slot, 0, bytes, v->stream);       // positions beyond the row's width stay zero
+    if (e == hipSuccess) {
+        if (plan.kind == 8)
+            e = launch_relayout_zquad(ori.src_plain, *slot, ori.srcD, ori.srcH, ori.pair_W, ori.pair_P, p.sPq, v->stream);
+        else
+            e = launch_relayout_zpair(ori.src_plain, *slot, ori.srcD, ori.srcH, ori.pair_W, ori.pair_P, p.sP2, v->stream);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(v->stream);                       // nothing may still be writing the buffer that is freed
+        (void)hipFree(*slot);
+        (void)hipGetLastError();
+        *slot = nullptr;
+        return 1;
+    }
+    if (plan.kind == 8) v->quad_bytes[ori.quad_idx] = bytes;
+    else v->P2 = p.sP2;
+    return 0;
+}
+
+// launch the plan's kernel into d_out (the secondary copy it reads exists: ensure_secondary_copy)
 int launch_planned(vt_volume* v, const TilePlan& plan, const AffineParams& p, const Orientation& ori, float* d_out, size_t n_out)
 {
     if (plan.kind == 8) {
-        if (!*ori.quad_slot) {
-            // the plane-quad copy of the (prefiltered) resident source; positions beyond the row's width stay zero
-            const size_t qbytes = (size_t)((ori.srcD + 3) / 4) * ori.srcH * p.sPq * sizeof(float);
-            VT_HIP(hipMalloc(reinterpret_cast<void**>(ori.quad_slot), qbytes));
-            v->quad_bytes[ori.quad_idx] = qbytes;
-            VT_HIP(hipMemsetAsync(*ori.quad_slot, 0, qbytes, v->stream));
-            VT_HIP(launch_relayout_zquad(ori.src_plain, *ori.quad_slot, ori.srcD, ori.srcH, ori.pair_W, ori.pair_P, p.sPq, v->stream));
-        }
+        if (!*ori.quad_slot) return fail(VT_EINVAL, "internal: plane-quad copy missing");
         VT_HIP(launch_affine_quad(plan.cfg, v->interp, *ori.quad_slot, d_out, p, plan.grid, plan.lds_bytes, v->stream));
     } else if (plan.kind == 5) {
-        if (!*ori.pair_slot) {
-            // the plane-pair copy of the (prefiltered) resident source
-            v->P2 = p.sP2;
-            const size_t zbytes = (size_t)((ori.srcD + 1) / 2) * ori.srcH * v->P2 * sizeof(float);
-            VT_HIP(hipMalloc(reinterpret_cast<void**>(ori.pair_slot), zbytes));
-            VT_HIP(hipMemsetAsync(*ori.pair_slot, 0, zbytes, v->stream));
-            VT_HIP(launch_relayout_zpair(ori.src_plain, *ori.pair_slot, ori.srcD, ori.srcH, ori.pair_W, ori.pair_P, v->P2, v->stream));
-        }
+        if (!*ori.pair_slot) return fail(VT_EINVAL, "internal: plane-pair copy missing");
         VT_HIP(launch_affine_zpair(plan.cfg, v->interp, *ori.pair_slot, d_out, p, plan.grid, plan.lds_bytes, v->stream));
     } else if (plan.kind == 9) {
         if (!v->d_queue) {
@@ -599,18 +625,31 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
         if (!std::isfinite(m[i])) return fail(VT_EINVAL, "matrix entry %d is not finite", i);
 
     AffineParams p;
-    std::memset(&p, 0, sizeof(p));
     TilePlan plan;
-    plan.kind = 0;
     Orientation ori;
-    ori.src_plain = v->d_src; ori.pair_slot = &v->d_src_zp; ori.quad_slot = &v->d_src_q; ori.quad_idx = 0;
-    ori.srcD = v->D; ori.srcH = v->H; ori.pair_W = v->W; ori.pair_P = v->P;
     const size_t n_out = (size_t)v->oD * v->oH * v->oW;
-    // single-axis rotations about axes 1 / 2 and in-plane maps near a quarter turn march on an exchanged resident copy
-    if ((rc = try_axis1_exchange(v, m, flags, n_out, &p, &plan, &ori))) return rc;
-    if (plan.kind == 0 && (rc = try_axis2_exchange(v, m, flags, n_out, &p, &plan, &ori))) return rc;
-    if (plan.kind == 0 && (rc = try_inplane_transposed(v, m, flags, n_out, &p, &plan, &ori))) return rc;
-    if (plan.kind == 0) plan_launch(v, m, flags, &p, &plan);
+    // Plan, then make sure the resident copy the plan reads exists.  A copy that cannot be built (device memory: a handle that has
+    // used every orientation holds up to 8 copies of its volume) takes its kernel family out of the running and the call is
+    // planned again: quad -> pair (cubic) / plain marching -> ... every family from kind 4 down reads the plain layout.
+    int deny = 0;
+    for (int attempt = 0;; ++attempt) {
+        std::memset(&p, 0, sizeof(p));
+        plan = TilePlan();
+        plan.kind = 0;
+        ori = Orientation();
+        ori.src_plain = v->d_src; ori.pair_slot = &v->d_src_zp; ori.quad_slot = &v->d_src_q; ori.quad_idx = 0;
+        ori.srcD = v->D; ori.srcH = v->H; ori.pair_W = v->W; ori.pair_P = v->P;
+        const int pf = flags | deny;
+        // single-axis rotations about axes 1 / 2 and in-plane maps near a quarter turn march on an exchanged resident copy
+        if ((rc = try_axis1_exchange(v, m, pf, n_out, &p, &plan, &ori))) return rc;
+        if (plan.kind == 0 && (rc = try_axis2_exchange(v, m, pf, n_out, &p, &plan, &ori))) return rc;
+        if (plan.kind == 0 && (rc = try_inplane_transposed(v, m, pf, n_out, &p, &plan, &ori))) return rc;
+        if (plan.kind == 0) plan_launch(v, m, pf, &p, &plan);
+        const int miss = ensure_secondary_copy(v, plan, p, ori);
+        if (miss == 0) break;
+        if (attempt >= 2) return fail(VT_EINVAL, "no kernel family can serve this call (secondary resident copies cannot be built)");
+        deny |= (plan.kind == 8) ? VT_NO_QUAD : VT_NO_ZPAIR;
+    }
 
     float* d_out = out;
     const bool host_out = !(flags & VT_OUT_DEVICE);
@@ -785,9 +824,10 @@ int create_common(int dev, int D, int H, int W, int interp, const float* data, i
 // against 19.8 ms sequential).  Requirements: an axis-0-separable matrix (each output plane taps a window of source
 // planes), only the plain resident layout (the secondary copies are built from a complete source).  filt_* interpolations:
 // the X and Y passes of the prefilter are plane-local and run per uploaded chunk; the axis-0 pass already works in chunks
-// of 64 / 128 planes with 16 planes of warm-up, so each of its chunks is launched as soon as those planes are there (same
-// kernels, same chunk grid: the coefficients are the resident volume's, bit for bit).  Returns 1 when the call does not
-// qualify.
+// of 64 / 128 planes with 16 planes of warm-up, so each of its chunks is launched as soon as those planes are there.  (A
+// resident volume filters axes 0 and 1 with the block-form kernel since round 2: the pipeline's coefficients agree with a
+// resident volume's to ~1e-9 relative, not bit for bit; tests/test_gpu_parity.py compares the two paths on filt_*.)  Returns 1
+// when the call does not qualify.
 // VT_PIPE_TRACE: host-side timeline and per-chunk event times of one pipelined one-shot call
 void pipeline_trace(double t_begin, double t_created, double t_pinned, double t_uploads, double t_slabs, double t_done, int nch,
                     const std::vector<hipEvent_t>& ev_up, const std::vector<hipEvent_t>& ev_k, const std::vector<hipEvent_t>& ev_dn)
@@ -912,7 +952,7 @@ int oneshot_pipelined(int dev, const float* h_volume, int D, int H, int W, int i
     const int lflags = (flags | VT_OUT_DEVICE | VT_NO_ZPAIR | VT_NO_QUAD | VT_NO_RSWAP) & ~VT_KEEP_OUTSIDE;
     // Kernel stream, per uploaded chunk: (filt_*) X and Y passes of the prefilter on the chunk's planes (plane-local), then
     // every axis-0 chunk of the prefilter whose input planes (its own + warm-up) are there, then every output slab whose
-    // source planes are final.  The prefilter runs the same kernels on the same chunk grid as for a resident volume.
+    // source planes are final.  The axis-0 pass uses the chunked kernel (prefilter_chunk_size / prefilter_warmup describe ITS grid).
     const int zC = filt ? prefilter_chunk_size(D) : 1;
     const int nzc = filt ? (D + zC - 1) / zC : 0;
     int z_chunks_done = 0, next_slab = 0;
@@ -1350,7 +1390,8 @@ int vt_volume_info(const vt_volume_t* v, vt_volume_info_t* info)
 {
     if (!v || !info) return fail(VT_EINVAL, "NULL argument");
     info->device = v->dev; info->interp = v->interp;
-    info->depth = v->D; info->height = v->H; info->width = v->W;
+    // the caller's dims: a VT_EDGE_SCIPY handle keeps edge_pad mirrored voxels on every side of the resident copy (v->D/H/W)
+    info->depth = v->D - 2 * v->edge_pad; info->height = v->H - 2 * v->edge_pad; info->width = v->W - 2 * v->edge_pad;
     info->out_depth = v->oD; info->out_height = v->oH; info->out_width = v->oW;
     info->last_kernel = v->last_kernel;
     for (int i = 0; i < 3; ++i) { info->last_tile[i] = v->last_tile[i]; info->last_lds_dims[i] = v->last_lds[i]; }
@@ -1361,6 +1402,11 @@ int vt_volume_info(const vt_volume_t* v, vt_volume_info_t* info)
                            (v->d_src_t ? plain : 0) +
                            (v->d_src_t_zp ? (uint64_t)((v->H + 1) / 2) * v->D * v->P2 * sizeof(float) : 0) +
                            (v->proj ? (uint64_t)3 * v->proj->H * v->proj->P * sizeof(float) : 0) +
+                           (v->d_src_r ? (uint64_t)v->D * v->W * v->Pr * sizeof(float) : 0) +
+                           (v->d_src_r_zp ? (uint64_t)((v->D + 1) / 2) * v->W * v->P2 * sizeof(float) : 0) +
+                           (v->d_src_x ? (uint64_t)v->W * v->H * v->Px * sizeof(float) : 0) +
+                           (v->d_src_x_zp ? (uint64_t)((v->W + 1) / 2) * v->H * v->P2 * sizeof(float) : 0) +
+                           (v->d_tmp_x ? (uint64_t)v->tmp_x_elems * sizeof(float) : 0) +
                            v->quad_bytes[0] + v->quad_bytes[1] + v->quad_bytes[2] + v->quad_bytes[3];
     return 0;
 }

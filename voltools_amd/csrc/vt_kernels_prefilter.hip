@@ -336,7 +336,7 @@ __global__ __launch_bounds__(64 * NW, 4) void prefilter_block(const float* __res
                                                           int N, int64_t es,          // line length, element stride along the line
                                                           int nA4,                    // columns / 4 (lane axis, contiguous, 16-byte vectors)
                                                           int nB, int64_t sB,         // outer axis
-                                                          int nseg, int lo_interior)
+                                                          int nseg, int lo_interior, int W)
 {
     constexpr int kBlkSeg = NW * kBlkCW - 2 * kBlkK;
     static_assert(kBlkCW >= 12, "the causal initialisation reads the first 12 samples from one chunk");
@@ -364,6 +364,18 @@ __global__ __launch_bounds__(64 * NW, 4) void prefilter_block(const float* __res
 #pragma unroll
     for (int k = 0; k < kBlkCW; ++k)
         v[k] = (k < cnt) ? *reinterpret_cast<const float4*>(s + (int64_t)(my0 + k) * es) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // The pad columns W .. roundup4(W)-1 of the last vector are filtered along with the data and written to dst, where the
+    // transform kernels read them as the border colour: whatever src holds there (a recycled ping-pong buffer), they enter as 0.
+    // Block-uniform branch: only the last column block of a width that is not a multiple of 4 pays for the selects.
+    if ((W & 3) && cb == ncb - 1) {
+        const int x0 = 4 * col4;
+#pragma unroll
+        for (int k = 0; k < kBlkCW; ++k) {
+            if (x0 + 1 >= W) v[k].y = 0.f;
+            if (x0 + 2 >= W) v[k].z = 0.f;
+            if (x0 + 3 >= W) v[k].w = 0.f;
+        }
+    }
 
     constexpr float z1 = kPole;
     float g = 1.0f;                                           // z^CW
@@ -528,7 +540,7 @@ hipError_t launch_prefilter_axis(int axis, const float* src, float* dst, int D, 
     if (!no_block && axis != 2 && src != dst && (pitch & 3) == 0 && pitch >= ((W + 3) & ~3) &&
         ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0 && (axis == 1 ? H : D) >= 40) {
         // block form (16 bytes per lane, exact carries): rows are 16-byte aligned and padded to whole vectors (the pad columns
-        // are filtered along with the rest: zeros stay zeros)
+        // of the last vector enter as zeros whatever src holds there, so dst's pad columns are zeros)
         const int N = axis == 1 ? H : D;
         const int64_t es = axis == 1 ? (int64_t)pitch : plane;
         const int nB = axis == 1 ? D : H;
@@ -539,7 +551,7 @@ hipError_t launch_prefilter_axis(int axis, const float* src, float* dst, int D, 
             const int nseg = (N + seg - 1) / seg;
             const int64_t blocks = (int64_t)((nA4 + 63) / 64) * nB * nseg;
             if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * nw), 0, stream, src, dst, N, es, nA4, nB, sB, nseg, lo_interior ? 1 : 0);
+            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * nw), 0, stream, src, dst, N, es, nA4, nB, sB, nseg, lo_interior ? 1 : 0, W);
             return hipGetLastError();
         };
         if (blk_variant == 1) return launch(prefilter_block<8, 20>, 8, 20);

@@ -304,6 +304,7 @@ bool plan_quad(PlanCtx& c)
     AffineParams* p = c.p;
     TilePlan* plan = c.plan;
     if (!c.zsep || (c.flags & (VT_NO_MARCH | VT_NO_QUAD | VT_NO_ZPAIR))) return false;
+    if (v->H > 65535 || (v->D + 3) / 4 > 65535) return false;      // relayout_zquad's grid (y = rows, z = quads): never plan what cannot be built
     const int halo = c.cubic ? 1 : 0;
     const int Wq = (v->W + 1 + 7) & ~7;                    // positions per quad-row: >= one zero position, rows of whole 128-byte lines
     const int64_t quad_bytes = (int64_t)v->H * Wq * 16;
@@ -432,6 +433,7 @@ bool plan_zpair(PlanCtx& c)
     AffineParams* p = c.p;
     TilePlan* plan = c.plan;
     if (!c.zsep || !c.cubic || (c.flags & (VT_NO_MARCH | VT_NO_ZPAIR))) return false;
+    if (v->H > 65535 || (v->D + 1) / 2 > 65535) return false;      // relayout_zpair's grid
     if ((int64_t)v->H * v->P * 4 >= 0x7fffffffLL || (int64_t)v->H * (2 * (((v->W + 3) & ~3) + 4)) * 4 >= 0x7fffffffLL) return false;
     const TilePlan saved = *plan;
     if (!zpair_pick_tile(c)) return false;

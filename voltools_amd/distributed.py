@@ -159,11 +159,18 @@ class SlabVolume:
             recv_bufs.append((buf, a, b))
             ops.append(dist.P2POp(dist.irecv, buf, self._global_rank(src), group))
         self.exchanged_bytes = sum((b - a) * H * W * 4 for _, a, b in recvs)
+        self.sent_bytes = sum((b - a) * H * W * 4 for _, a, b in sends)
+        # the path's only communication: timed (wall clock, this rank) so that bench.py can print it next to the step time
+        import time
+        if on_gpu:
+            torch.cuda.synchronize(tdev)
+        t_halo = time.perf_counter()
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
         if on_gpu:
             torch.cuda.synchronize(tdev)
+        self.halo_ms = (time.perf_counter() - t_halo) * 1e3
 
         if engine is not None:
             window = torch.zeros((w1 - w0, H, W), dtype=torch.float32, device=tdev)
