@@ -54,7 +54,7 @@ def test_bench_self_launch_ranks_share_one_gpu(world, strong):
 def test_bench_forced_slab_path_matches_plain_path():
     """One rank through SlabVolume (a 1-rank RCCL group, the N > 1 code path) against the plain StaticVolume path: same kernel,
     same launch geometry; kernel time within 10 % (measured: within 2 %, see profiles/)."""
-    args = ['--gpus', '1', '--size', '256', '--interp', 'bspline', '--steps', '60', '--warmup', '5', '--prewarm-ms', '100',
+    args = ['--gpus', '1', '--size', '512', '--interp', 'bspline', '--steps', '60', '--warmup', '5', '--prewarm-ms', '100',
             '--no-cpu-baseline', '--no-extra-1024']
     plain = run_bench(args)
     slab = run_bench(args, {'BENCH_FORCE_SLAB': '1', 'MASTER_PORT': '29577'})

@@ -23,6 +23,7 @@ ap.add_argument('--env', nargs='*', default=[''], help='environment variants, e.
 ap.add_argument('--angles', nargs=3, type=float, default=[0, 180, 5])
 ap.add_argument('--rounds', type=int, default=3)
 ap.add_argument('--reps', type=int, default=3)
+ap.add_argument('--per-angle', action='store_true', help='print the per-angle times of every variant')
 args = ap.parse_args()
 
 n = args.size
@@ -71,6 +72,8 @@ for interp in args.interp:
         worst = angles[int(np.argmax(t))]
         print(f'{interp:14s} {n}^3 flags={f:5d} env={e or "-":24s} kernel={k[0]} tile={k[1]} lds={k[2]} grid={k[3]}: '
               f'mean {t.mean():.4f} ms  min {t.min():.4f}  max {t.max():.4f} (at {worst:.0f} deg)  {tb:.2f} TB/s = {tb / 8 * 100:.1f} %', flush=True)
+        if args.per_angle:
+            print('    ' + ' '.join(f'{a:.0f}:{x * 1e3:.0f}' for a, x in zip(angles, t)), flush=True)
     seen = set()
     for e, f, sv in variants:
         if id(sv) not in seen:

@@ -24,6 +24,9 @@ struct Tuning {
     int quad_rows = -2;            // VT_QUAD_ROWS: -1 = rows packed back to back, 0..15 = force the row stride S of the bank-aware placement, -2 = planner
     int quad_grid2d = 1;           // VT_QUAD_GRID2D=0: 1-D grid with XCD-contiguous ids over all chunks (round-2 A/B)
     int quad_reverse = -1;         // VT_QUAD_REVERSE: 1 / 0 = the 2-D grid walks the in-plane tiles in descending / ascending order, -1 = planner
+    int quad_perm = 1;             // VT_QUAD_PERM=0: identity lane -> pixel mapping in the plane-quad kernel (round-3 A/B)
+    int quad_zid = 1;              // VT_QUAD_ZID=0: trilinear launches with fz == 0 keep the two-plane kernel (round-3 A/B)
+    int zid_dch = 0;               // VT_ZID_DCH: chunk depth of the integer-offset trilinear kernel (0 = the trilinear default)
     int quad_nt = -1;              // VT_QUAD_NT: 1 / 0 = nontemporal / plain output stores of the plane-quad kernel, -1 = planner's choice
     bool no_block = false;         // VT_NO_BLOCK_KERNEL: general matrices on the round-1 box / packed kernels
     int block_rs = -1;             // VT_BLOCK_RS: force the row-stride index of the lane-block kernel (if it holds the box)
@@ -49,6 +52,9 @@ struct Tuning {
         exp_nolds = std::getenv("VT_EXP_NOLDS") != nullptr;
         exp_noloop = std::getenv("VT_EXP_NOLOOP") != nullptr;
         quad_nt = num("VT_QUAD_NT", -1);
+        quad_perm = num("VT_QUAD_PERM", 1);
+        quad_zid = num("VT_QUAD_ZID", 1);
+        zid_dch = num("VT_ZID_DCH", 0);
         quad_reverse = num("VT_QUAD_REVERSE", -1);
         quad_grid2d = num("VT_QUAD_GRID2D", 1);
         quad_rows = num("VT_QUAD_ROWS", -2);

@@ -214,7 +214,7 @@ hipError_t launch_relayout_swap01(const float* src, float* dst, int D, int H, in
 int quad_max_it();
 int quad_config_count();
 void quad_config(int idx, int* th, int* tw, int* nt);
-int quad_blocks_per_cu(int cfg, int interp, int lds_bytes);
+int quad_blocks_per_cu(int cfg, int interp, int lds_bytes, bool zid = false);
 hipError_t init_quad_kernels();
 hipError_t launch_relayout_zquad(const float* src, float* dst, int D, int H, int W, int P, int Pq, hipStream_t stream);
 hipError_t launch_affine_quad(int cfg, int interp, const float* srcq, float* out, const AffineParams& p,

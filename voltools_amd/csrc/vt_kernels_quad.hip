@@ -20,6 +20,17 @@
 //     predicate-free body; everything else (first / last step of a chunk, tiles cut by the skirt or the output edge)
 //     takes the general body.
 // Per output voxel (trilinear): one ds_read_b128, ~5 VALU, 1 store, < 0.1 scalar instructions.
+//
+// Round 3:
+//   * KIND 3 = trilinear with an INTEGER axis-0 offset (fz == 0: every rotation about axis 0, every in-plane map).  The weight of
+//     the second tap plane is exactly 0, so output plane d is the in-plane interpolation of source plane d + zoff alone
+//     (fmaf(0, b - a, a) == a for finite data: bit-identical to KIND 0).  No carried partial, and a chunk of dch output planes reads
+//     exactly dch / 4 quads instead of dch / 4 + 1: the history quad was 1/8 of a 32-plane chunk's staged bytes.
+//   * Lanes are assigned to pixels so that every 16-lane service group of ds_read_b128 (MI355X_MICROARCH.md, LDS:
+//     {0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) holds 16 CONSECUTIVE pixels of a pixel row: inside one source row their taps are
+//     then consecutive 16-byte slots whatever the angle (the identity mapping spreads a group over 28 pixels, i.e. 24 slots at
+//     30 degrees: conflicts by construction).  [model, tools/quad_conflict_sim.py] with bank-aware row starts: 1.67 -> 1.12
+//     LDS cycles per read at 15 degrees, 2.0 -> 1.31 at 20.  The store of a wave still covers the same two 128-byte row segments.
 #include "vt_internal.h"
 #include <mutex>
 #include <unordered_map>
@@ -70,7 +81,7 @@ template <int KIND>
 __device__ __forceinline__ void quad_gather_column(const float* __restrict__ srcq, float* __restrict__ out, const AffineParams& p, int64_t oo,
                                                 int d_begin, int d_end, bool in_yx, int gy0, int gx0, float fy, float fx)
 {
-    constexpr bool CUBIC = KIND != 0;
+    constexpr bool CUBIC = KIND == 1 || KIND == 2;
     const bool keep = (p.flags & VT_KEEP_OUTSIDE) != 0;
     auto fetch = [&](int z, int y, int x) -> float {
         if ((unsigned)z < (unsigned)p.sD && (unsigned)y < (unsigned)p.sH && (unsigned)x < (unsigned)p.sW)
@@ -117,14 +128,34 @@ __device__ __forceinline__ void quad_gather_column(const float* __restrict__ src
     }
 }
 
+// pixel position (0..63 within the wave's 64 pixels) of a lane, and its inverse: each ds_read_b128 service group gets 16 consecutive
+// positions.  Piecewise shifts of 4-lane blocks inside each half-wave: lanes 0-3 | 4-11 | 12-15 | 16-19 | 20-27 | 28-31 go to
+// positions 0-3 | 16-23 | 4-7 | 24-27 | 8-15 | 28-31.
+__device__ __forceinline__ int quad_lane_to_pos(int lane)
+{
+    const int blk = (lane >> 2) & 7;                       // 4-lane block inside the half-wave
+    // shift in units of 4 positions, biased by +3, one nibble per block: {0, +3, +3, -2, +2, -3, -3, 0}
+    const int sh = (int)((0x30051663u >> (4 * blk)) & 15u) - 3;
+    return lane + 4 * sh;
+}
+__device__ __forceinline__ int quad_pos_to_lane(int pos)
+{
+    const int blk = (pos >> 2) & 7;
+    // inverse shifts: {0, +2, +3, +3, -3, -3, -2, 0}
+    const int sh = (int)((0x31006653u >> (4 * blk)) & 15u) - 3;
+    return pos + 4 * sh;
+}
+
 template <int KIND, int TH, int TW, int NT>
 __global__ __launch_bounds__(NT) void affine_march4(const float* __restrict__ srcq, float* __restrict__ out, const AffineParams p)
 {
-    static_assert(NT % TW == 0 && TH % (NT / TW) == 0 && NT % 64 == 0, "tile/thread mapping");
-    constexpr bool CUBIC = KIND != 0;
+    static_assert(NT % TW == 0 && TH % (NT / TW) == 0 && NT % 64 == 0 && 64 % TW == 0, "tile/thread mapping");
+    constexpr bool CUBIC = KIND == 1 || KIND == 2;
+    constexpr bool ZID = KIND == 3;               // trilinear, integer axis-0 offset: one tap plane per output plane
     constexpr int HALO = CUBIC ? 1 : 0;
     constexpr int NR = 2 + 2 * HALO;              // tap rows (and columns) per pixel
-    constexpr int NC = 2 * HALO + 1;              // carried in-plane partials per pixel
+    constexpr int NC = 2 * HALO + 1;              // carried in-plane partials per pixel (unused for ZID)
+    constexpr int ZNEW = ZID ? 0 : 1;             // the newest tap plane of output d is d + zoff + HALO + ZNEW
     constexpr int RP = NT / TW;
     constexpr int NPIX = TH / RP;
     constexpr int NSTORE = 4 * NPIX;              // store instructions of a full step (one per pixel and plane)
@@ -173,8 +204,15 @@ __global__ __launch_bounds__(NT) void affine_march4(const float* __restrict__ sr
     all_valid = all_valid && (z_lo >= p.vlo[0] + kTileMargin) && (z_hi < p.vhi[0] - kTileMargin);
     const bool keep = (p.flags & VT_KEEP_OUTSIDE) != 0;
     const int64_t ostride = p.ostride, orow = p.orow;     // element strides of an output plane / row (axis swaps)
-    const int kw = tid % TW;
-    const int jh0 = tid / TW;
+    // lane -> pixel: position `pos` of the wave's 64 pixels (TW | 64: a pixel row never straddles a wave)
+    const bool lane_perm = (p.flags & (1 << 23)) != 0;
+    const int lane_id = tid & 63;
+    const int pos = lane_perm ? quad_lane_to_pos(lane_id) : lane_id;
+    const int kw = pos % TW;
+    const int jh0 = (tid >> 6) * (64 / TW) + pos / TW;
+    // lanes holding the neighbouring pixels of the pixel row (used where kw > 0 / kw < TW - 1 only)
+    const int lane_left = lane_perm ? quad_pos_to_lane((pos + 63) & 63) : ((lane_id + 63) & 63);
+    const int lane_right = lane_perm ? quad_pos_to_lane((pos + 1) & 63) : ((lane_id + 1) & 63);
 
     if (!any_valid) {
         if (!keep) {
@@ -243,7 +281,7 @@ __global__ __launch_bounds__(NT) void affine_march4(const float* __restrict__ sr
 #pragma unroll
         for (int px = 0; px < NPIX; ++px) {
             // neighbours along the pixel row (TW divides 64: a pixel row never straddles a wave)
-            const int iy_l = __shfl_up(iy[px], 1), iy_r = __shfl_down(iy[px], 1);
+            const int iy_l = __shfl(iy[px], lane_left), iy_r = __shfl(iy[px], lane_right);
             const bool edge = (kw == 0) || (kw == TW - 1) || (iy_l != iy[px]) || (iy_r != iy[px]);
             if (edge) {
 #pragma unroll
@@ -349,7 +387,7 @@ __global__ __launch_bounds__(NT) void affine_march4(const float* __restrict__ sr
     const int quad_bytes = p.sH * p.sPq * 4;      // bytes of one resident quad-plane, < 2^31 (host-checked)
     const int nquads_res = (p.sD + 3) >> 2;
     // first / last source plane any output of the chunk taps, and the quads holding them
-    const int plane_first = d_begin + p.zoff - HALO, plane_last = d_end - 1 + p.zoff + HALO + 1;
+    const int plane_first = d_begin + p.zoff - HALO, plane_last = d_end - 1 + p.zoff + HALO + ZNEW;
     const int Q0 = floordiv4(plane_first), QN = floordiv4(plane_last);
     const int Q_base = max(0, min(Q0, nquads_res - 1));
     // source: one descriptor for the chunk, based at the first resident quad it touches; the quad is selected with the scalar offset
@@ -363,7 +401,7 @@ __global__ __launch_bounds__(NT) void affine_march4(const float* __restrict__ sr
     float wz[4] = {0.f, 0.f, 0.f, 0.f};
     if constexpr (CUBIC) cubic_weights<KIND == 2>(fz, wz);
     // steps whose four outputs all belong to the chunk: quads Qf0 .. Qf1 (output d's newest tap plane is d + zoff + HALO + 1)
-    const int tap_new = p.zoff + HALO + 1;
+    const int tap_new = p.zoff + HALO + ZNEW;
     const int Qf0 = floordiv4(d_begin + tap_new + 3), Qf1 = floordiv4(d_end - 4 + tap_new);
     const bool nt_stores = (p.flags & (1 << 28)) != 0;       // streaming (nontemporal) output stores, chosen by the planner
     const bool tile_fast = all_valid && (h0 + TH <= p.oH) && (w0 + TW <= p.oW);
@@ -439,7 +477,9 @@ __global__ __launch_bounds__(NT) void affine_march4(const float* __restrict__ sr
         // axis-0 combination of one new plane partial with the carried ones (same order as the other kernels)
         auto zcombine = [&](int px, float pn) -> float {
             float val;
-            if constexpr (!CUBIC) {
+            if constexpr (ZID) {
+                val = pn;                          // == fmaf(0, next - pn, pn) for finite data
+            } else if constexpr (!CUBIC) {
                 val = fmaf(fz, pn - carry[px][0], carry[px][0]);
                 carry[px][0] = pn;
             } else {
@@ -547,6 +587,7 @@ static quad_fn pick_quad(int kind)
     switch (kind) {
         case 0: return affine_march4<0, TH, TW, NT>;
         case 1: return affine_march4<1, TH, TW, NT>;
+        case 3: return affine_march4<3, TH, TW, NT>;
         default: return affine_march4<2, TH, TW, NT>;
     }
 }
@@ -564,7 +605,7 @@ static quad_fn quad_entry(int cfg, int kind)
 hipError_t init_quad_kernels()
 {
     for (int cfg = 0; cfg < quad_config_count(); ++cfg)
-        for (int kind = 0; kind < 3; ++kind) {
+        for (int kind = 0; kind < 4; ++kind) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(quad_entry(cfg, kind)),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
@@ -574,11 +615,11 @@ hipError_t init_quad_kernels()
 
 // Workgroups of this kernel that one CU keeps resident (register- and LDS-limited), from the runtime's occupancy
 // calculator; cached per (kernel, LDS size) -- the planner calls this on the per-call path.
-int quad_blocks_per_cu(int cfg, int interp, int lds_bytes)
+int quad_blocks_per_cu(int cfg, int interp, int lds_bytes, bool zid)
 {
     static std::mutex mu;
     static std::unordered_map<uint64_t, int> cache;
-    const int kind = interp_kind(interp);
+    const int kind = (zid && interp_kind(interp) == 0) ? 3 : interp_kind(interp);
     const uint64_t key = ((uint64_t)cfg << 34) | ((uint64_t)kind << 32) | (uint32_t)lds_bytes;
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(key);
@@ -596,7 +637,8 @@ int quad_blocks_per_cu(int cfg, int interp, int lds_bytes)
 hipError_t launch_affine_quad(int cfg, int interp, const float* srcq, float* out, const AffineParams& p,
                               int grid, int lds_bytes, hipStream_t stream)
 {
-    quad_fn fn = quad_entry(cfg, interp_kind(interp));
+    const bool zid = (p.flags & (1 << 25)) != 0 && interp_kind(interp) == 0;      // set by plan_quad when fz == 0 exactly
+    quad_fn fn = quad_entry(cfg, zid ? 3 : interp_kind(interp));
     const dim3 g = (p.flags & (1 << 29)) ? dim3((unsigned)(p.nTh * p.nTw), (unsigned)p.nTd) : dim3((unsigned)grid);
     hipLaunchKernelGGL(fn, g, dim3(kQuad[cfg].nt), lds_bytes, stream, srcq, out, p);
     return hipGetLastError();

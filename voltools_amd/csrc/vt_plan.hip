@@ -323,6 +323,10 @@ bool plan_quad(PlanCtx& c)
     p->zero_off_q = v->W * 16;
     p->flags = (c.flags & VT_KEEP_OUTSIDE) | experiment_flags(v);
     if (v->tune.quad_nt < 0 ? true : v->tune.quad_nt != 0) p->flags |= (1 << 28);     // streaming output stores ([measured] +2..5 % in-process)
+    if (v->tune.quad_perm != 0) p->flags |= (1 << 23);                                // lanes <-> pixels by ds_read_b128 service groups
+    // trilinear with an integer axis-0 offset (every rotation about axis 0): one tap plane per output plane, no history quad
+    const bool zid = !c.cubic && p->fz == 0.0f && v->tune.quad_zid != 0;
+    if (zid) p->flags |= (1 << 25);
     const int64_t inplane = (int64_t)p->nTh * p->nTw;
     // chunk depth: every chunk pays one quad step beyond its own planes (history of the first outputs), so chunks are deeper than
     // the plain kernels' -- but short-lived workgroups keep the write stream compact (tools/probes/pattern_probe.hip).
@@ -331,6 +335,7 @@ bool plan_quad(PlanCtx& c)
     // 512^3 0.227 ms at 64 planes, 0.233 at 128, 0.236 at 256
     // (2-D grid, blockIdx.y = chunk: trilinear 1024^3 1.593 ms at 32 planes, 1.609 at 48, 1.663 at 64, 1.702 at 128; 512^3 flat 16..64)
     int target_dch = c.cubic ? 64 : (((int64_t)v->H * v->W <= 512 * 512) ? 24 : 32);
+    if (zid && v->tune.zid_dch > 0) target_dch = v->tune.zid_dch;
     if (v->tune.dch > 0) target_dch = std::max(4, v->tune.dch);
     int64_t nchunks = std::max<int64_t>(1, (v->oD + target_dch - 1) / target_dch);
     // small volumes: shorter chunks until the launch has ~4 workgroups per CU, not below 8 planes per chunk
@@ -339,7 +344,7 @@ bool plan_quad(PlanCtx& c)
     // scalar byte offsets: source quads of a chunk from its first quad, output planes from its first plane (31 bits each)
     const int64_t n_addr = std::max(((int64_t)(v->oD / 4 + 4) * quad_bytes) / 0x60000000LL + 1, ((int64_t)v->oD * max_stride * 4) / 0x60000000LL + 1);
     nchunks = std::max<int64_t>(nchunks, n_addr);
-    plan->blocks_per_cu = quad_blocks_per_cu(plan->cfg, v->interp, plan->lds_bytes);
+    plan->blocks_per_cu = quad_blocks_per_cu(plan->cfg, v->interp, plan->lds_bytes, zid);
     int dch = (int)((v->oD + nchunks - 1) / nchunks);
     dch = (dch + 3) & ~3;
     // chunk boundaries at c*dch + dshift: the first tap plane of every chunk but the first, d_begin + zoff - halo, is then the
