@@ -166,8 +166,14 @@ int estimate_span_positions(const double m[12], int th, int tw, int halo, int ro
 // tap is (ix + iy * S) & 15 for its tap origin (iy, ix) -- the same for every tap of the 4 x 4 stencil.  The model evaluates two
 // waves of a 256-thread workgroup at two sub-voxel tile positions and returns the S with the fewest LDS cycles per read
 // (*factor: cycles relative to conflict-free).  ~3 us.
-int quad_row_stride(const double m[12], int th, int tw, double* factor)
+int quad_row_stride(const double m[12], int th, int tw, double* factor, bool lane_perm)
 {
+    // lane -> pixel position of the kernel (quad_lane_to_pos, vt_kernels_quad.hip): each service group = 16 consecutive positions
+    auto lane_pos = [&](int lane) {
+        if (!lane_perm) return lane;
+        static const int sh[8] = {0, 3, 3, -2, 2, -3, -3, 0};
+        return lane + 4 * sh[(lane >> 2) & 7];
+    };
     static const int kGroup[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
                                       {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
     const double a1 = m[5], b1 = m[6], a2 = m[9], b2 = m[10];
@@ -180,7 +186,7 @@ int quad_row_stride(const double m[12], int th, int tw, double* factor)
         for (int wave = 0; wave < 4; wave += 2, ++ns) {
             const double by = 0.29 + 0.42 * off - neg1 + 1.0, bx = 0.17 + 0.55 * off - neg2 + 1.0;
             for (int l = 0; l < 64; ++l) {
-                const int tid = 64 * wave + l, k = tid % tw, j = tid / tw;
+                const int pos = lane_pos(l), k = pos % tw, j = wave * (64 / tw) + pos / tw;
                 iy[ns][l] = (int)std::floor(by + a1 * j + b1 * k);
                 ix[ns][l] = (int)std::floor(bx + a2 * j + b2 * k);
             }
@@ -277,11 +283,19 @@ bool quad_pick_tile(PlanCtx& c, int64_t max_stride)
         // workgroups per CU (the kernel's register allocation admits no more) -- i.e. up to ~25 degrees for a 16 x 32 tile; a tile
         // whose padded image overflows the slot packs its rows back to back instead (in the kernel)
         p->row_s = -1;
-        if (c.cubic && v->tune.quad_rows != -1 && (int64_t)v->oD * v->oH * v->oW >= 128LL * 128 * 128) {
+        // (a map without axis-1 shear along a pixel row, m[1][2] == 0, keeps every 16-pixel group inside one source row: conflict-free
+        // however the rows are packed -- [measured] 0 degrees: 0.204 ms packed, 0.216 aligned)
+        if (c.cubic && v->tune.quad_rows != -1 && (int64_t)v->oD * v->oH * v->oW >= 128LL * 128 * 128 &&
+            (c.m[6] != 0.0 || v->tune.quad_rows >= 0 || v->tune.quad_perm == 0)) {
             const int padded64 = (npos + 9 * rows + 63) & ~63;
             if (padded64 <= nt * quad_max_it() && 2LL * padded64 * 16 <= 40 * 1024) {
                 double f = 0;
-                const int S = (v->tune.quad_rows >= 0) ? (v->tune.quad_rows & 15) : quad_row_stride(c.m, th, tw, &f);
+                // With lanes assigned by service groups a group's taps are 16 consecutive pixels: column-aligned rows (S = 0: slot =
+                // column mod 16) leave only the row crossings with an unchanged column as conflicts.  [measured, tools/r3_ab3.sh, 512^3
+                // cubic, 61 angles] S = 0: 0.2142 ms; the 16-candidate model's S: 0.2234; identity lanes + model (round 2): 0.2222;
+                // rows packed back to back: 0.2242 (with 0.29-0.30 ms outliers at 39 / 51 degrees).  The model serves VT_QUAD_PERM=0.
+                const int S = (v->tune.quad_rows >= 0) ? (v->tune.quad_rows & 15)
+                              : (v->tune.quad_perm != 0 ? 0 : quad_row_stride(c.m, th, tw, &f, false));
                 p->row_s = S;
                 nvec64 = padded64;
             }
@@ -335,6 +349,10 @@ bool plan_quad(PlanCtx& c)
     // 512^3 0.227 ms at 64 planes, 0.233 at 128, 0.236 at 256
     // (2-D grid, blockIdx.y = chunk: trilinear 1024^3 1.593 ms at 32 planes, 1.609 at 48, 1.663 at 64, 1.702 at 128; 512^3 flat 16..64)
     int target_dch = c.cubic ? 64 : (((int64_t)v->H * v->W <= 512 * 512) ? 24 : 32);
+    // integer-offset trilinear: no history quad, so short chunks cost only their set-up; [measured, tools/r3_ab1.sh] 1024^3: 1.476 ms at
+    // 16 planes, 1.509 at 24, 1.518 at 32, 1.568 at 48, 1.595 at 64 (the copy structure alone behaves the same: front_probe);
+    // 512^3: 0.1961 at 24, 0.1979 at 16, 0.1992 at 32
+    if (zid) target_dch = ((int64_t)v->H * v->W > 512 * 512) ? 16 : 20;       // 512^3: 0.1922 at 20, 0.1936 at 24, 0.1953 at 12 (tools/r3_ab2.sh)
     if (zid && v->tune.zid_dch > 0) target_dch = v->tune.zid_dch;
     if (v->tune.dch > 0) target_dch = std::max(4, v->tune.dch);
     int64_t nchunks = std::max<int64_t>(1, (v->oD + target_dch - 1) / target_dch);
