@@ -314,22 +314,27 @@ __global__ __launch_bounds__(NT) void affine_march4(const float* __restrict__ sr
                 // Bank-aware row starts (cubic): row r starts at a slot = x0 + r * S (mod 16), i.e. the image behaves like a box
                 // with row stride S in the 16-slot bank space of ds_read_b128 while only the spans are stored.  The gaps (< 16
                 // vectors per row) are filled from the zero vector.  S comes from the host's model of the gather's lane groups
-                // (vt_plan.hip: quad_row_stride): [model] conflict cycles per read 2.2-2.9x -> 1.0-1.7x below 20 degrees, ~2x above.
-                // Placement is sequential in the row index: one scalar pass over the wave's lanes.  If the padded image does
+                // (vt_plan.hip: S = 0 with the service-group lane mapping, quad_row_stride's model otherwise).  If the padded image does
                 // not fit the slot, the unpadded prefix sum above stays.
-                int pos = 0, first_p = 0, pad_p = 0;
+                // Every row start is pinned to a residue c_r = (x0_r + r * S) mod 16, so the gap in front of row r depends on its
+                // predecessor alone: gap_r = (c_r - c_{r-1} - n_{r-1}) mod 16 -- the placement is one more prefix sum, not a walk over
+                // the rows (round 2 walked them with readlane in a scalar loop: ~35 dependent iterations while three waves waited).
+                // Rows in use are contiguous (the footprint is convex); the rows before the first one carry residue 0 and length 0.
                 const int S = p.row_s;
-                unsigned long long todo = __ballot(nv > 0);       // rows in use (a third to a half of the 64): visit only those
-                while (todo) {
-                    const int r = __builtin_ctzll(todo);
-                    todo &= todo - 1;
-                    const int nv_r = __builtin_amdgcn_readlane(nv, r);
-                    const int x0_r = __builtin_amdgcn_readlane(x0, r);
-                    const int gap = (x0_r + r * S - pos) & 15;
-                    pos += gap;
-                    if (lane == r) { first_p = pos; pad_p = gap; }
-                    pos += nv_r;
+                const int c_r = (x0 + lane * S) & 15;
+                const int end_res = (nv > 0) ? ((c_r + nv) & 15) : 0;            // residue of the position right behind this row
+                int prev_end = __shfl_up(end_res, 1);
+                const int prev_nv = __shfl_up(nv, 1);
+                if (lane == 0 || prev_nv == 0) prev_end = 0;                     // first row in use: the image starts at position 0
+                const int gap = (nv > 0) ? ((c_r - prev_end) & 15) : 0;
+                int inc2 = gap + nv;
+#pragma unroll
+                for (int s2 = 1; s2 < 64; s2 <<= 1) {
+                    const int up = __shfl_up(inc2, s2);
+                    if (lane >= s2) inc2 += up;
                 }
+                const int first_p = inc2 - nv, pad_p = gap;
+                const int pos = __shfl(inc2, 63);
                 if (((pos + 63) & ~63) * 16 <= p.slot_floats * 4 && pos <= NT * kQuadMaxIt) { first = first_p; pad = pad_p; total = pos; }
             }
             tab[lane] = x0;
