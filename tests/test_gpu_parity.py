@@ -248,7 +248,11 @@ def test_prefilter_matches_oracle_all_axes_lengths():
     # (the last four: rows of whole 16-byte vectors -> the block-form strided passes; one segment, segments with warm-up at
     #  interior ends, partial last chunks, a last segment shorter than the warm-up)
     for shape in [(5, 7, 9), (12, 11, 13), (64, 65, 63), (130, 20, 70), (20, 200, 24), (24, 20, 300), (200, 17, 129),
-                  (300, 260, 64), (100, 530, 32), (36, 257, 8), (270, 40, 260)]:
+                  (300, 260, 64), (100, 530, 32), (36, 257, 8), (270, 40, 260),
+                  # rows of whole 8-sample lanes, lines of >= 40: X and Y fused in one kernel (prefilter_xy) -- one row segment, row
+                  # segments with warm-up, a last segment shorter than the warm-up, column segments (W > 512), H at the tile edge
+                  (3, 161, 64), (5, 200, 72), (2, 40, 520), (4, 300, 1000), (6, 128, 512), (3, 160, 96), (2, 45, 64), (3, 129, 136),
+                  (2, 400, 992)]:
         vol = rand_vol(shape, 5)
         d = _native.DeviceArray.from_numpy(vol, 0)
         _native.check(lib.vt_prefilter_inplace(0, d.ptr, *shape), 'vt_prefilter_inplace')
@@ -256,6 +260,20 @@ def test_prefilter_matches_oracle_all_axes_lengths():
         want = oracle.prefilter(vol)
         assert np.abs(got - want).max() <= 5e-6, shape
         d.free()
+
+
+@pytest.mark.parametrize('shape', [(20, 47, 67), (9, 170, 101), (4, 290, 515), (3, 41, 64), (5, 161, 481)])
+def test_prefilter_fused_xy_on_pitched_rows(shape):
+    """The fused X+Y pass on the resident (pitched) layout, widths that are not multiples of 4 or 8: the identity transform of a
+    filt_bspline volume returns the prefiltered-then-resampled samples; against the oracle on the whole volume."""
+    vol = rand_vol(shape, 17)
+    m = np.eye(4, dtype=np.float32)
+    m[:3, 3] = (0.25, -0.5, 0.125)                  # sub-voxel shift: every coefficient takes part
+    sv = vt.StaticVolume(vol, interpolation='filt_bspline', device='gpu:0')
+    got = sv.affine(m)
+    want = oracle.affine(vol, m, 'filt_bspline')
+    assert np.abs(got - want).max() <= TOL['filt_bspline'], shape
+    sv.close()
 
 
 def test_prefilter_known_answers():

@@ -329,7 +329,14 @@ int run_prefilter(float* d_a, float* d_b, int D, int H, int W, int P, bool lo_in
     float* cur = d_a;
     float* oth = d_b;
     const int order[3] = {2, 1, 0};
-    for (int i = 0; i < 3; ++i) {
+    int first_pass = 0;
+    if (prefilter_xy_ok(D, H, W, P)) {
+        // X and Y in one launch (vt_kernels_prefilter.hip: prefilter_xy): the plane is read once and written once for both
+        VT_HIP(launch_prefilter_xy(cur, oth, D, H, W, P, st));
+        float* t = cur; cur = oth; oth = t;
+        first_pass = 2;
+    }
+    for (int i = first_pass; i < 3; ++i) {
         const int axis = order[i];
         const bool interior = (axis == 0) && lo_interior_axis0;
         if (prefilter_axis_in_place_ok(axis, D, H, W)) {
@@ -964,8 +971,12 @@ int oneshot_pipelined(int dev, const float* h_volume, int D, int H, int W, int i
         int final_planes = z1;                     // source planes [0, final_planes) hold what the transform samples
         if (filt) {
             const size_t off = (size_t)z0 * H * v->P;
-            VT_HIPP(launch_prefilter_axis(2, v->d_src + off, v->d_src + off, z1 - z0, H, W, v->P, false, s_k));
-            VT_HIPP(launch_prefilter_axis(1, v->d_src + off, d_tmp + off, z1 - z0, H, W, v->P, false, s_k));
+            if (prefilter_xy_ok(z1 - z0, H, W, v->P)) {
+                VT_HIPP(launch_prefilter_xy(v->d_src + off, d_tmp + off, z1 - z0, H, W, v->P, s_k));
+            } else {
+                VT_HIPP(launch_prefilter_axis(2, v->d_src + off, v->d_src + off, z1 - z0, H, W, v->P, false, s_k));
+                VT_HIPP(launch_prefilter_axis(1, v->d_src + off, d_tmp + off, z1 - z0, H, W, v->P, false, s_k));
+            }
             int c1 = z_chunks_done;
             while (c1 < nzc && std::min(D, (c1 + 1) * zC + prefilter_warmup()) <= z1) ++c1;
             if (c1 > z_chunks_done) {

@@ -24,6 +24,7 @@
 //     one write per sample, and a 512^3 pass exposes 2M independent lanes instead of 262144.
 //     Chunked passes read neighbours' samples, so they run out of place (ping-pong buffers).
 #include "vt_internal.h"
+#include "vt_device.h"
 
 #include <cstdlib>
 
@@ -455,6 +456,244 @@ __global__ __launch_bounds__(64 * NW, 4) void prefilter_block(const float* __res
             if (k < cnt && pos >= a0 && pos < b0) *reinterpret_cast<float4*>(o + (int64_t)pos * es) = v[k];
         }
     }
+}
+
+// ---- X and Y passes in ONE kernel (round 3): a 1024-thread workgroup owns a 160-row x 512-column tile of one plane, in registers ----
+// Three separate passes move 24 bytes per sample.  The X pass works along contiguous rows and the Y pass across them, so a tile
+// that holds WHOLE rows (8 consecutive samples per lane: a wave covers 512 columns with two 16-byte loads per lane) can run the X
+// recursion on each of its rows inside the wave that holds it -- serial over a lane's 8 samples, the carry between lanes a two-step
+// scan with ratio z^8 = 2.7e-5 (the next term, z^32, is 5e-19) -- and then the Y recursion down its columns exactly as
+// prefilter_block does: NW waves stacked along the line, CW rows each, local sweeps with zero carry-in, exact carries through LDS.
+// The plane is read once and written once: 8 + 8 bytes per sample for two passes, plus the warm-up rows of interior row segments
+// (16 on either side of 128: 1.25x reads, which meet the neighbouring segment's loads in L2 when they run together).  Rows wider
+// than 512 are cut into column segments of 480 + 16 warm-up columns on interior sides.  Arithmetic per sample: the reference's
+// recursion (bspline.h:30-54) with its initialisations at true line ends, re-associated like the other kernels here.
+constexpr int kXyNW = 16, kXyCW = 10, kXyK = 16;
+constexpr int kXyRows = kXyNW * kXyCW, kXyNetRows = kXyRows - 2 * kXyK;        // 160 loaded, 128 written
+constexpr int kXyCols = 512, kXyNetCols = kXyCols - 2 * kXyK;                   // 512 loaded, 480 written (interior column segments)
+
+template <int NW, int CW>
+__global__ __launch_bounds__(64 * NW) void prefilter_xy(const float* __restrict__ src, float* __restrict__ dst,
+                                                         int H, int W, int pitch, int64_t plane, int nsegY, int nsegX)
+{
+    constexpr float z1 = kPole, z2 = z1 * z1, z3 = z2 * z1, z4 = z2 * z2, z5 = z4 * z1, z6 = z4 * z2, z7 = z4 * z3, z8 = z4 * z4, z16 = z8 * z8;
+    constexpr float zp[9] = {1.0f, z1, z2, z3, z4, z5, z6, z7, z8};
+    __shared__ float ends[NW][8][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // consecutive tiles (the row segments of one plane, then the next plane) go to ONE XCD: the segments of a plane are resident
+    // together there and their overlapping warm-up rows meet in that XCD's L2
+    int t = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int sx = t % nsegX; t /= nsegX;
+    const int sy = t % nsegY;
+    const int zpl = t / nsegY;
+
+    // columns: [na, nb) are written, [la, lb) loaded; rows likewise
+    const bool one_x = nsegX == 1, one_y = nsegY == 1;
+    const int na = one_x ? 0 : sx * kXyNetCols, nb = one_x ? W : min(na + kXyNetCols, W);
+    const int la = one_x ? 0 : max(na - kXyK, 0), lb = one_x ? W : min(nb + kXyK, W);
+    const int ra = one_y ? 0 : sy * (NW * CW - 2 * kXyK), rb = one_y ? H : min(ra + (NW * CW - 2 * kXyK), H);
+    const int lra = one_y ? 0 : max(ra - kXyK, 0), lrb = one_y ? H : min(rb + kXyK, H);
+    const int r0 = lra + w * CW;                              // this wave's rows [r0, r0 + cnt)
+    const int cnt = max(0, min(CW, lrb - r0));
+    const int x0 = la + 8 * lane;                             // this lane's columns [x0, x0 + 8)
+    const bool lane_on = x0 < lb;
+    const float* s = src + (int64_t)zpl * plane + x0;
+    float* o = dst + (int64_t)zpl * plane + x0;
+
+    float v[CW][8];
+#pragma unroll
+    for (int k = 0; k < CW; ++k) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        if (k < cnt && lane_on) {
+            const float* rp = s + (int64_t)(r0 + k) * pitch;
+            a = *reinterpret_cast<const float4*>(rp);
+            b = *reinterpret_cast<const float4*>(rp + 4);          // stays inside the row's pitch (host-checked: pitch >= roundup8(W))
+        }
+        v[k][0] = a.x; v[k][1] = a.y; v[k][2] = a.z; v[k][3] = a.w; v[k][4] = b.x; v[k][5] = b.y; v[k][6] = b.z; v[k][7] = b.w;
+    }
+    // samples at columns >= lb are not part of this segment's line (pitch padding, or the next segment's columns): they enter as 0
+    if (x0 + 8 > lb) {
+#pragma unroll
+        for (int k = 0; k < CW; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (x0 + j >= lb) v[k][j] = 0.f;
+    }
+
+    // ================= X pass: every row of this wave, inside the wave =================
+    const int lastx = lb - 1;                                 // the true line end, or an interior end (steady-state guess there)
+    const int hx = W < 12 ? W : 12;                           // horizon of the causal initialisation
+#pragma unroll
+    for (int k = 0; k < CW; ++k) {
+        float* a = v[k];
+        // causal, local: l[j] = L a[j] + z l[j-1], zero carry-in; lane 0 starts from the initialisation
+        float first = kLambda * a[0];
+        if (la == 0) {
+            // bspline.h:2-19: L (s[0] + sum_{n < min(12, N)} z^(n+1) s[n]); samples 0..7 in lane 0, 8..11 in lane 1
+            float part = 0.f;
+            if (lane == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (j < hx) part = fmaf(zp[j + 1], a[j], part);
+            } else if (lane == 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (8 + j < hx) part = fmaf(z8 * zp[j + 1], a[j], part);
+            }
+            const float tot = __shfl(part, 0) + __shfl(part, 1);
+            if (lane == 0) first = kLambda * (a[0] + tot);
+        } else if (lane == 0) {
+            first = kLambda * (1.0f / (1.0f - kPole)) * a[0];  // interior start: steady state of a constant signal, forgotten after K samples
+        }
+        a[0] = first;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) a[j] = fmaf(z1, a[j - 1], kLambda * a[j]);
+        // true end state of every lane: E[l] = e[l] + z^8 E[l-1]
+        float e = a[7], u;
+        u = __shfl_up(e, 1); e = (lane >= 1) ? fmaf(z8, u, e) : e;
+        u = __shfl_up(e, 2); e = (lane >= 2) ? fmaf(z16, u, e) : e;
+        float cin = __shfl_up(e, 1);
+        cin = (lane == 0) ? 0.f : cin;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = fmaf(zp[j + 1], cin, a[j]);
+        // anticausal: c[n] = u[n] + z c[n+1]; u[last] = z/(z-1) c+[last], u[n < last] = -z c+[n], u[n > last] = 0
+#pragma unroll
+        for (int j = 7; j >= 0; --j) {
+            const int x = x0 + j;
+            const float uj = (x < lastx) ? (-z1) * a[j] : ((x == lastx) ? kAntiInit * a[j] : 0.f);
+            a[j] = (j == 7) ? uj : fmaf(z1, a[j + 1], uj);
+        }
+        float st = a[0];
+        u = __shfl_down(st, 1); st = (lane < 63) ? fmaf(z8, u, st) : st;
+        u = __shfl_down(st, 2); st = (lane < 62) ? fmaf(z16, u, st) : st;
+        float cr = __shfl_down(st, 1);
+        cr = (lane == 63) ? 0.f : cr;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = fmaf(zp[8 - j], cr, a[j]);
+    }
+    // (columns >= lb hold exact zeros again: u = 0 there and nothing flows in from beyond the line)
+
+    // ================= Y pass: down the columns, CW rows per wave, exact carries through LDS =================
+    float g = 1.0f;                                           // z^CW
+#pragma unroll
+    for (int k = 0; k < CW; ++k) g *= z1;
+    const int hy = H < 12 ? H : 12;
+    const bool y_start = (lra == 0);                          // this segment holds row 0 (in wave 0)
+    if (y_start && hy > CW) {
+        // the causal initialisation reads rows 0..11: rows CW..11 live in wave 1 -- hand their weighted sum over
+        if (w == 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float part = 0.f;
+                float zn = g * z1;                            // z^(CW+1): weight of row CW
+#pragma unroll
+                for (int k = 0; k < 12 - CW; ++k) {
+                    if (CW + k < hy) part = fmaf(zn, v[k][j], part);
+                    zn *= z1;
+                }
+                ends[0][j][lane] = part;
+            }
+        }
+        __syncthreads();
+    }
+    if (w == 0 && cnt > 0) {
+        if (y_start) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float sum = v[0][j];
+                float zn = z1;
+#pragma unroll
+                for (int k = 0; k < CW; ++k) {
+                    if (k < hy) sum = fmaf(zn, v[k][j], sum);
+                    zn *= z1;
+                }
+                if (hy > CW) sum += ends[0][j][lane];
+                v[0][j] = kLambda * sum;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[0][j] = kLambda * (1.0f / (1.0f - kPole)) * v[0][j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[0][j] = kLambda * v[0][j];
+    }
+#pragma unroll
+    for (int k = 1; k < CW; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[k][j] = fmaf(z1, v[k - 1][j], kLambda * v[k][j]);
+    // (wave 0 overwrites ends[0] only after it has read the hand-over itself; no other wave writes ends[0])
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ends[w][j][lane] = v[CW - 1][j];
+    __syncthreads();
+    if (w > 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float c = ends[0][j][lane];
+            for (int i = 1; i < w; ++i) c = fmaf(g, c, ends[i][j][lane]);
+            float zk = z1;
+#pragma unroll
+            for (int k = 0; k < CW; ++k) { v[k][j] = fmaf(zk, c, v[k][j]); zk *= z1; }
+        }
+    }
+    __syncthreads();
+    // anticausal, local: positions >= lrb are padding (u = 0)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float c = 0.f;
+#pragma unroll
+        for (int k = CW - 1; k >= 0; --k) {
+            const int pos = r0 + k;
+            float u;
+            if (k >= cnt) u = 0.f;
+            else if (pos == lrb - 1) u = kAntiInit * v[k][j];                 // the line's end, or an interior end (steady-state guess)
+            else u = (-z1) * v[k][j];
+            c = fmaf(z1, c, u);
+            v[k][j] = c;
+        }
+        ends[w][j][lane] = v[0][j];
+    }
+    __syncthreads();
+    if (w < NW - 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float c = ends[NW - 1][j][lane];
+            for (int i = NW - 2; i > w; --i) c = fmaf(g, c, ends[i][j][lane]);
+            float zk = z1;
+#pragma unroll
+            for (int k = CW - 1; k >= 0; --k) { v[k][j] = fmaf(zk, c, v[k][j]); zk *= z1; }
+        }
+    }
+
+    // ---- store rows [ra, rb) x columns [na, nb); behind the line's end the vector is completed with zeros (the pitch padding) ----
+    const int nb_st = (nb == W) ? ((W + 3) & ~3) : nb;
+    const bool st0 = x0 >= na && x0 < nb_st, st1 = x0 + 4 >= na && x0 + 4 < nb_st;
+#pragma unroll
+    for (int k = 0; k < CW; ++k) {
+        const int pos = r0 + k;
+        if (k < cnt && pos >= ra && pos < rb) {
+            float* rp = o + (int64_t)pos * pitch;
+            if (st0) *reinterpret_cast<float4*>(rp) = make_float4(v[k][0], v[k][1], v[k][2], v[k][3]);
+            if (st1) *reinterpret_cast<float4*>(rp + 4) = make_float4(v[k][4], v[k][5], v[k][6], v[k][7]);
+        }
+    }
+}
+
+// X + Y in one launch where the tile shape pays: rows of >= 64 samples, lines of >= 40; 16-byte aligned rows whose pitch holds whole
+// 8-sample lanes.  Returns false when the shape does not qualify (the caller runs the two passes separately).
+bool prefilter_xy_ok(int D, int H, int W, int pitch)
+{
+    static const bool off = getenv("VT_PF_NO_XY") != nullptr;
+    return !off && W >= 64 && H >= 40 && (pitch & 3) == 0 && pitch >= ((W + 7) & ~7) && (int64_t)D * ((H + 127) / 128) * ((W + 479) / 480) < 0x7fffffffLL;
+}
+
+hipError_t launch_prefilter_xy(const float* src, float* dst, int D, int H, int W, int pitch, hipStream_t stream)
+{
+    if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) != 0 || src == dst) return hipErrorInvalidValue;
+    const int nsegY = (H <= kXyRows) ? 1 : (H + kXyNetRows - 1) / kXyNetRows;
+    const int nsegX = (W <= kXyCols) ? 1 : (W + kXyNetCols - 1) / kXyNetCols;
+    const int64_t blocks = (int64_t)D * nsegY * nsegX;
+    hipLaunchKernelGGL((prefilter_xy<kXyNW, kXyCW>), dim3((unsigned)blocks), dim3(64 * kXyNW), 0, stream,
+                       src, dst, H, W, pitch, (int64_t)H * pitch, nsegY, nsegX);
+    return hipGetLastError();
 }
 
 constexpr int kChunk = 64, kWarm = 16;
