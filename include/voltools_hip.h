@@ -142,6 +142,11 @@ int vt_volume_create_slab(int dev, int local_depth, int height, int width, int i
 int vt_volume_upload_planes(vt_volume_t* vol, int first_plane, int nplanes, const float* data, int flags);
 int vt_volume_finalize(vt_volume_t* vol);
 
+/* 1 when the library is the test build that also carries round 1's kernel families (plain / plane-pair marching, kernels 4 / 5, and
+ * the axis-0-separable box kernel, 3): `make LEGACY=1`.  The product build returns 0; VT_NO_QUAD / VT_NO_ZPAIR / VT_NO_MARCH then
+ * send an axis-0-separable matrix to the general-matrix kernels.  (No reference counterpart: diagnostic.) */
+int vt_has_legacy_kernels(void);
+
 int vt_volume_destroy(vt_volume_t* vol);
 int vt_volume_info(const vt_volume_t* vol, vt_volume_info_t* info);
 int vt_volume_stream(const vt_volume_t* vol, void** hip_stream);   /* the hipStream_t launches go to */

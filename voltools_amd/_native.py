@@ -30,7 +30,7 @@ SYMBOLS = [
     'vt_volume_sync', 'vt_volume_set_output_shape', 'vt_volume_affine', 'vt_volume_affine_f64',
     'vt_volume_project', 'vt_volume_project_f64', 'vt_volume_affine_batch',
     'vt_timer_start', 'vt_timer_stop', 'vt_prefilter_inplace', 'vt_affine_oneshot',
-    'vt_last_error', 'vt_version',
+    'vt_last_error', 'vt_version', 'vt_has_legacy_kernels',
 ]
 
 
@@ -81,6 +81,7 @@ def load():
     L = ctypes.CDLL(LIB_PATH)
     c_int, c_void_p, c_size_t, c_i64 = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int64
     P = ctypes.POINTER
+    L.vt_has_legacy_kernels.argtypes = []
     L.vt_device_count.argtypes = [P(c_int)]
     L.vt_device_name.argtypes = [c_int, ctypes.c_char_p, c_int]
     L.vt_device_props.argtypes = [c_int, P(c_int), P(c_int), P(ctypes.c_uint64)]
@@ -128,6 +129,11 @@ def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = load().vt_last_error()
         raise RuntimeError(f'{what} failed (code {rc}): {msg.decode() if msg else "?"}')
+
+
+def has_legacy_kernels() -> bool:
+    """True for the test build (`make LEGACY=1`: round 1's marching kernels 4 / 5 and the axis-0-separable box kernel 3 compiled in)."""
+    return bool(load().vt_has_legacy_kernels())
 
 
 def device_count() -> int:

@@ -549,9 +549,11 @@ int ensure_secondary_copy(vt_volume* v, const TilePlan& plan, const AffineParams
     if (plan.kind == 8) {
         slot = ori.quad_slot;
         bytes = (size_t)((ori.srcD + 3) / 4) * ori.srcH * p.sPq * sizeof(float);
+#ifdef VT_LEGACY
     } else if (plan.kind == 5) {
         slot = ori.pair_slot;
         bytes = (size_t)((ori.srcD + 1) / 2) * ori.srcH * p.sP2 * sizeof(float);
+#endif
     } else return 0;
     if (*slot) return 0;
     if (hipMalloc(reinterpret_cast<void**>(slot), bytes) != hipSuccess) {
@@ -563,8 +565,10 @@ int ensure_secondary_copy(vt_volume* v, const TilePlan& plan, const AffineParams
     if (e == hipSuccess) {
         if (plan.kind == 8)
             e = launch_relayout_zquad(ori.src_plain, *slot, ori.srcD, ori.srcH, ori.pair_W, ori.pair_P, p.sPq, v->stream);
+#ifdef VT_LEGACY
         else
             e = launch_relayout_zpair(ori.src_plain, *slot, ori.srcD, ori.srcH, ori.pair_W, ori.pair_P, p.sP2, v->stream);
+#endif
     }
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -585,9 +589,11 @@ int launch_planned(vt_volume* v, const TilePlan& plan, const AffineParams& p, co
     if (plan.kind == 8) {
         if (!*ori.quad_slot) return fail(VT_EINVAL, "internal: plane-quad copy missing");
         VT_HIP(launch_affine_quad(plan.cfg, v->interp, *ori.quad_slot, d_out, p, plan.grid, plan.lds_bytes, v->stream));
+#ifdef VT_LEGACY
     } else if (plan.kind == 5) {
         if (!*ori.pair_slot) return fail(VT_EINVAL, "internal: plane-pair copy missing");
         VT_HIP(launch_affine_zpair(plan.cfg, v->interp, *ori.pair_slot, d_out, p, plan.grid, plan.lds_bytes, v->stream));
+#endif
     } else if (plan.kind == 9) {
         if (!v->d_queue) {
             VT_HIP(hipMalloc(reinterpret_cast<void**>(&v->d_queue), 9 * 128));
@@ -596,8 +602,10 @@ int launch_planned(vt_volume* v, const TilePlan& plan, const AffineParams& p, co
         VT_HIP(launch_affine_block(plan.cfg, v->interp, v->d_src, d_out, v->d_zeros, v->d_queue, p, plan.geo, plan.grid, plan.lds_bytes, v->stream));
     } else if (plan.kind == 6) {
         VT_HIP(launch_affine_packed(plan.cfg, v->interp, v->d_src, d_out, v->d_zeros, p, plan.geo, plan.grid, plan.lds_bytes, v->stream));
+#ifdef VT_LEGACY
     } else if (plan.kind == 4) {
         VT_HIP(launch_affine_march(plan.cfg, v->interp, ori.src_plain, d_out, p, plan.grid, plan.lds_bytes, v->stream));
+#endif
     } else if (plan.kind >= 2) {
         VT_HIP(launch_affine_tiled(plan.cfg, v->interp, plan.kind == 3, v->d_src, d_out, v->d_zeros, p, plan.grid, plan.lds_bytes, v->stream));
     } else {
@@ -1395,6 +1403,15 @@ int vt_volume_destroy(vt_volume_t* v)
     if (v->stream && v->owns_stream) recycle_stream(v->dev, v->stream);
     delete v;
     return 0;
+}
+
+int vt_has_legacy_kernels(void)
+{
+#ifdef VT_LEGACY
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 int vt_volume_info(const vt_volume_t* v, vt_volume_info_t* info)

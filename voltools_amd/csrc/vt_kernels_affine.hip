@@ -214,6 +214,7 @@ __global__ __launch_bounds__(256) void affine_tiled(const float* __restrict__ sr
     }
 }
 
+#ifdef VT_LEGACY      // kernel 3 (box kernel with in-plane partial reuse for axis-0-separable matrices): test build only
 // ---------------------------------------------------------------------------------------------------
 // axis-0-separable tiled kernel
 // ---------------------------------------------------------------------------------------------------
@@ -378,6 +379,8 @@ __global__ __launch_bounds__(256) void affine_tiled_zsep(const float* __restrict
     }
 }
 
+#endif  // VT_LEGACY
+
 // ---------------------------------------------------------------------------------------------------
 // direct kernel: one thread per output voxel, taps from global memory with explicit border tests
 // ---------------------------------------------------------------------------------------------------
@@ -461,6 +464,7 @@ typedef void (*tiled_fn)(const float*, float*, const float*, const AffineParams)
 template <int TD, int TH, int TW>
 static tiled_fn pick_tiled(int kind, bool zsep)
 {
+#ifdef VT_LEGACY
     if (zsep) {
         switch (kind) {
             case 0: return affine_tiled_zsep<0, TD, TH, TW>;
@@ -468,6 +472,7 @@ static tiled_fn pick_tiled(int kind, bool zsep)
             default: return affine_tiled_zsep<2, TD, TH, TW>;
         }
     }
+#endif
     switch (kind) {
         case 0: return affine_tiled<0, TD, TH, TW>;
         case 1: return affine_tiled<1, TD, TH, TW>;
@@ -500,12 +505,20 @@ hipError_t init_affine_kernels()
     // dynamic LDS above 64 KiB needs an explicit opt-in per kernel; gfx950 has 160 KiB per workgroup
     for (int cfg = 0; cfg < tile_config_count(); ++cfg)
         for (int kind = 0; kind < 3; ++kind)
+#ifdef VT_LEGACY
             for (int z = 0; z < 2; ++z) {
+#else
+            for (int z = 0; z < 1; ++z) {
+#endif
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tiled_entry(cfg, kind, z != 0)),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 if (e != hipSuccess) return e;
             }
+#ifdef VT_LEGACY
     return init_march_kernels();
+#else
+    return hipSuccess;
+#endif
 }
 
 hipError_t launch_affine_tiled(int cfg, int interp, bool zsep, const float* src, float* out, const float* zeros16,

@@ -1,4 +1,10 @@
-// vt_kernels_march.hip -- the axis-0-separable *marching* transform kernel (gfx950).
+// vt_kernels_march.hip -- the round-1 axis-0-separable *marching* transform kernels (gfx950): plain layout (kernel 4) and
+// plane-pair layout (kernel 5).  Since round 3 they are compiled only into the test build (`make LEGACY=1`, -DVT_LEGACY): the
+// plane-quad kernel (vt_kernels_quad.hip) serves every launch they served, and the planner census (tools/planner_census.py)
+// shows them chosen nowhere but for 4x in-plane minification of cubic volumes, which the box kernel now takes.  They stay as
+// independent implementations for cross-checks (tests/test_gpu_legacy.py).  The axis-exchange relayout and the footprint-table
+// constants that the current kernels share live at the top of this file.
+//
 //
 // Matrices of the block form  [1 0 0 tz; 0 a b ty; 0 c d tx]  (rotations about axis 0 -- the README sweep
 // `rotate((0, i, 0))` and every BASELINE configuration --, in-plane scale/shear, any translation): the source plane of an
@@ -32,6 +38,30 @@
 #include <type_traits>
 
 namespace vt {
+
+// plain [z][y][P] -> [y][z][P] (axes 0 and 1 exchanged; whole rows incl. the zero pad move as 16-byte vectors)
+__global__ __launch_bounds__(256) void relayout_swap01(const float4* __restrict__ src, float4* __restrict__ dst, int D, int H, int P4)
+{
+    const int xv = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y, z = blockIdx.z;
+    if (xv >= P4) return;
+    dst[((int64_t)y * D + z) * P4 + xv] = src[((int64_t)z * H + y) * P4 + xv];
+}
+
+hipError_t launch_relayout_swap01(const float* src, float* dst, int D, int H, int P, hipStream_t stream)
+{
+    const dim3 grid((P / 4 + 255) / 256, H, D);
+    if (grid.y > 65535 || grid.z > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(relayout_swap01, grid, dim3(256), 0, stream, reinterpret_cast<const float4*>(src),
+                       reinterpret_cast<float4*>(dst), D, H, P / 4);
+    return hipGetLastError();
+}
+
+int march_rows_max() { return kRowsMax; }
+int march_table_bytes() { return kTabBytes; }
+
+#ifdef VT_LEGACY
+
 
 // in-plane partial of one source plane for one pixel; q[] = LDS float offsets of the tap rows inside the plane slot
 template <int KIND, int NR>
@@ -796,24 +826,6 @@ __global__ __launch_bounds__(256) void relayout_zpair(const float* __restrict__ 
     *o = make_float2(a, b);
 }
 
-// plain [z][y][P] -> [y][z][P] (axes 0 and 1 exchanged; whole rows incl. the zero pad move as 16-byte vectors)
-__global__ __launch_bounds__(256) void relayout_swap01(const float4* __restrict__ src, float4* __restrict__ dst, int D, int H, int P4)
-{
-    const int xv = blockIdx.x * 256 + threadIdx.x;
-    const int y = blockIdx.y, z = blockIdx.z;
-    if (xv >= P4) return;
-    dst[((int64_t)y * D + z) * P4 + xv] = src[((int64_t)z * H + y) * P4 + xv];
-}
-
-hipError_t launch_relayout_swap01(const float* src, float* dst, int D, int H, int P, hipStream_t stream)
-{
-    const dim3 grid((P / 4 + 255) / 256, H, D);
-    if (grid.y > 65535 || grid.z > 65535) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(relayout_swap01, grid, dim3(256), 0, stream, reinterpret_cast<const float4*>(src),
-                       reinterpret_cast<float4*>(dst), D, H, P / 4);
-    return hipGetLastError();
-}
-
 hipError_t launch_relayout_zpair(const float* src, float* dst, int D, int H, int W, int P, int P2, hipStream_t stream)
 {
     const dim3 grid((W + 255) / 256, H, (D + 1) / 2);
@@ -843,9 +855,7 @@ void march_config(int idx, int* th, int* tw, int* g, int* la, int* nt)
 {
     *th = kMarch[idx].th; *tw = kMarch[idx].tw; *g = kMarch[idx].g; *la = kMarch[idx].la; *nt = kMarch[idx].nt;
 }
-int march_rows_max() { return kRowsMax; }
 int march_max_it() { return kMaxIt; }
-int march_table_bytes() { return kTabBytes; }
 
 template <int TH, int TW, int G, int LA, int NT>
 static march_fn pick_march(int kind)
@@ -959,5 +969,7 @@ hipError_t launch_affine_march(int cfg, int interp, const float* src, float* out
     hipLaunchKernelGGL(fn, dim3(grid), dim3(kMarch[cfg].nt), lds_bytes, stream, src, out, p);
     return hipGetLastError();
 }
+
+#endif  // VT_LEGACY
 
 }  // namespace vt

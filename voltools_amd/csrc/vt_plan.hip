@@ -7,11 +7,13 @@
 //
 //   family   kind  kernel (file)                                   serves
 //   quad       8   affine_march4       (vt_kernels_quad.hip)       axis-0-separable matrices, every interpolation
-//   zpair      5   affine_march_zpair  (vt_kernels_march.hip)      axis-0-separable, cubic   (VT_NO_QUAD)
-//   march      4   affine_march_zsep   (vt_kernels_march.hip)      axis-0-separable          (VT_NO_QUAD / VT_NO_ZPAIR)
-//   box      2, 3  affine_tiled[_zsep] (vt_kernels_affine.hip)     any matrix whose tile footprint's bounding box fits LDS
+//   block      9   affine_block        (vt_kernels_block.hip)      general matrices, cubic, outputs >= 256^3
+//   box        2   affine_tiled        (vt_kernels_affine.hip)     any matrix whose tile footprint's bounding box fits LDS
 //   packed     6   affine_tiled_packed (vt_kernels_packed.hip)     invertible general matrices, trilinear (or forced)
 //   direct     1   affine_direct       (vt_kernels_affine.hip)     everything else (tiny volumes, huge footprints)
+// Test build only (`make LEGACY=1`): zpair 5 / march 4 (vt_kernels_march.hip: round 1's plane-pair and plain marching kernels) and
+// kind 3 (affine_tiled_zsep, the box kernel with in-plane partial reuse) -- round 3's planner census (tools/planner_census.py) found
+// them chosen for nothing but 4x in-plane minification of cubic volumes, which the box kernel serves.
 #include "vt_host.h"
 #include "vt_device.h"
 
@@ -32,6 +34,7 @@ struct PlanCtx {
     int halo2;                 // extra taps of the cubic stencil on each side (0 / 2 in total)
 };
 
+#ifdef VT_LEGACY      // helpers of the round-1 marching families (test build only)
 // Chunk count of a marching launch.  Its workgroups all do the same work, so the chip runs them in rounds of `resident`
 // workgroups and a launch of 5.33 rounds takes almost as long as one of 6 ([measured] 512^3 cubic at 0 / 30 degrees:
 // 8 chunks = 5.33 rounds 0.274 / 0.304 ms; 6 chunks = 4.0 rounds 0.261 / 0.296; 3 chunks = 2.0 rounds 0.249 / 0.297;
@@ -129,6 +132,8 @@ int estimate_packed_vectors(const double m[12], int th, int tw, int halo, int ro
     return worst + worst / 64 + 2;
 }
 
+
+#endif  // VT_LEGACY
 
 // Upper estimate of the packed footprint of a TH x TW in-plane tile in POSITIONS (plane-quad layout: one 16-byte vector per
 // position, no alignment), as affine_march4 packs it.  A 3 x 3 grid of sub-voxel offsets is sampled; a row's span changes by
@@ -390,6 +395,7 @@ bool plan_quad(PlanCtx& c)
     return true;
 }
 
+#ifdef VT_LEGACY      // round-1 families: test build only (see kFamilies)
 // ---------------------------------------------------------------------------------------------------
 // zpair: cubic marching kernel on the plane-pair layout (kind 5)
 // ---------------------------------------------------------------------------------------------------
@@ -594,6 +600,8 @@ bool plan_march(PlanCtx& c)
     plan->grid = (int)grid;
     return true;
 }
+
+#endif  // VT_LEGACY
 
 // ---------------------------------------------------------------------------------------------------
 // box: 3-D tiles, bounding box of the footprint staged (kinds 2, 3)
@@ -935,8 +943,10 @@ typedef bool (*plan_fn)(PlanCtx&);
 struct Family { const char* name; plan_fn plan; };
 const Family kFamilies[] = {
     {"quad", plan_quad},        // axis-0-separable, plane-quad layout
-    {"zpair", plan_zpair},      // axis-0-separable cubic, plane-pair layout
-    {"march", plan_march},      // axis-0-separable, plain layout
+#ifdef VT_LEGACY
+    {"zpair", plan_zpair},      // axis-0-separable cubic, plane-pair layout (test build)
+    {"march", plan_march},      // axis-0-separable, plain layout (test build)
+#endif
     {"block", plan_block},      // 3-D tiles: lane blocks on a bank-tuned box (rotations, mild scale / shear)
     {"general", plan_general},  // 3-D tiles: bounding boxes vs packed footprints
 };
@@ -989,8 +999,14 @@ void plan_launch(const vt_volume* v, const double m[12], int flags, AffineParams
     c.cubic = is_cubic(v->interp);
     c.halo2 = c.cubic ? 2 : 0;           // cubic taps reach one voxel further on each side
     c.zsep = !(flags & VT_NO_ZSEP) && m[0] == 1.0 && m[1] == 0.0 && m[2] == 0.0 && m[4] == 0.0 && m[8] == 0.0 && std::fabs(m[3]) < 1.0e9;
-    for (const Family& f : kFamilies)
+    for (const Family& f : kFamilies) {
         if (f.plan(c)) return;
+#ifndef VT_LEGACY
+        // the round-1 axis-0-separable families (plain / plane-pair marching, the box kernel with in-plane partial reuse) exist in the
+        // test build only: a separable matrix the plane-quad kernel declines is planned as a general matrix
+        if (f.plan == plan_quad) c.zsep = false;
+#endif
+    }
     plan->kind = 1;                       // nothing tiled fits: direct gather
 }
 
