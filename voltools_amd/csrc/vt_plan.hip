@@ -296,7 +296,7 @@ bool quad_pick_tile(PlanCtx& c, int64_t max_stride)
             if (padded64 <= nt * quad_max_it() && 2LL * padded64 * 16 <= 40 * 1024) {
                 double f = 0;
                 // With lanes assigned by service groups a group's taps are 16 consecutive pixels: column-aligned rows (S = 0: slot =
-                // column mod 16) leave only the row crossings with an unchanged column as conflicts.  [measured, tools/r3_ab3.sh, 512^3
+                // column mod 16) leave only the row crossings with an unchanged column as conflicts.  [measured, tools/r3_quad_ab.sh rows -> profiles/r03_ab_3_rows.txt, 512^3
                 // cubic, 61 angles] S = 0: 0.2142 ms; the 16-candidate model's S: 0.2234; identity lanes + model (round 2): 0.2222;
                 // rows packed back to back: 0.2242 (with 0.29-0.30 ms outliers at 39 / 51 degrees).  The model serves VT_QUAD_PERM=0.
                 const int S = (v->tune.quad_rows >= 0) ? (v->tune.quad_rows & 15)
@@ -354,10 +354,10 @@ bool plan_quad(PlanCtx& c)
     // 512^3 0.227 ms at 64 planes, 0.233 at 128, 0.236 at 256
     // (2-D grid, blockIdx.y = chunk: trilinear 1024^3 1.593 ms at 32 planes, 1.609 at 48, 1.663 at 64, 1.702 at 128; 512^3 flat 16..64)
     int target_dch = c.cubic ? 64 : (((int64_t)v->H * v->W <= 512 * 512) ? 24 : 32);
-    // integer-offset trilinear: no history quad, so short chunks cost only their set-up; [measured, tools/r3_ab1.sh] 1024^3: 1.476 ms at
+    // integer-offset trilinear: no history quad, so short chunks cost only their set-up; [measured, tools/r3_quad_ab.sh zid -> profiles/r03_ab_1_zid.txt] 1024^3: 1.476 ms at
     // 16 planes, 1.509 at 24, 1.518 at 32, 1.568 at 48, 1.595 at 64 (the copy structure alone behaves the same: front_probe);
     // 512^3: 0.1961 at 24, 0.1979 at 16, 0.1992 at 32
-    if (zid) target_dch = ((int64_t)v->H * v->W > 512 * 512) ? 16 : 20;       // 512^3: 0.1922 at 20, 0.1936 at 24, 0.1953 at 12 (tools/r3_ab2.sh)
+    if (zid) target_dch = ((int64_t)v->H * v->W > 512 * 512) ? 16 : 20;       // 512^3: 0.1922 at 20, 0.1936 at 24, 0.1953 at 12 (tools/r3_quad_ab.sh depth -> profiles/r03_ab_2_depth.txt)
     if (zid && v->tune.zid_dch > 0) target_dch = v->tune.zid_dch;
     if (v->tune.dch > 0) target_dch = std::max(4, v->tune.dch);
     int64_t nchunks = std::max<int64_t>(1, (v->oD + target_dch - 1) / target_dch);
