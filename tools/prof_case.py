@@ -17,6 +17,7 @@ ap.add_argument('--interp', default='linear')
 ap.add_argument('--angle', type=float, default=45.0)
 ap.add_argument('--axis1', action='store_true', help='rotation by --angle about array axis 1 (sxyz (0, angle, 0))')
 ap.add_argument('--axis2', action='store_true', help='rotation by --angle about array axis 2 (sxyz (0, 0, angle))')
+ap.add_argument('--sweep', type=float, default=0.0, help='README sweep: rotate((0, i, 0)) for i = 0, step, 2 step, ... < 180 instead of one angle')
 ap.add_argument('--general', action='store_true', help='general 3-D rotation (25,-40,70) sxyz instead of in-plane')
 ap.add_argument('--case', default='', help='named matrix from tests/test_gpu_parity.py MATRICES (overrides --angle/--general)')
 ap.add_argument('--iters', type=int, default=10)
@@ -46,12 +47,15 @@ if args.case:
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
     from test_gpu_parity import MATRICES
     m = MATRICES[args.case]((n, n, n))
-for _ in range(3):
-    sv.affine(m, output=out, _flags=args.flags)
+mats = [m]
+if args.sweep > 0:
+    mats = [vt.utils.transform_matrix(rotation=(0, float(a), 0), rotation_order='rzxz', center=c) for a in np.arange(0.0, 180.0, args.sweep)]
+for mm in (mats if args.sweep > 0 else [m] * 3):
+    sv.affine(mm, output=out, _flags=args.flags)        # (a sweep runs once untimed: the lazily built resident copies exist afterwards)
 sv.synchronize()
 sv.timer_start()
-for _ in range(args.iters):
-    sv.affine(m, output=out, _flags=args.flags)
+for i in range(args.iters):
+    sv.affine(mats[i % len(mats)], output=out, _flags=args.flags)
 ms = sv.timer_stop() / args.iters
 info = sv.info()
 print(f'{args.interp} {n}^3 angle={args.angle} general={args.general} case={args.case} kernel={info.last_kernel}: {ms:.4f} ms/launch, '

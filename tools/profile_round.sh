@@ -3,9 +3,9 @@
 #   1. rocprofv3 --kernel-trace --stats          -> per-kernel average durations
 #   2. separate --pmc passes (never combined with tracing): HBM-side traffic, L2 hit rate, SQ issue / wait, LDS conflicts
 # and one summary JSON per command under gpurun_out/profiles_<tag>/ (copy what should be judged into profiles/).
-# usage: tools/profile_round.sh <tag> [case ...]     cases: bench sweep1024 general512 prefilter1024 linear1024 (default: all)
+# usage: tools/profile_round.sh <tag> [case ...]     cases: bench linear512 sweep1024 linear1024 general512 prefilter512 prefilter1024 (default: all)
 tag=${1:-r02}; shift
-cases=${@:-bench sweep1024 linear1024 general512 prefilter1024}
+cases=${@:-bench linear512 sweep1024 linear1024 general512 prefilter512 prefilter1024}
 export TMPDIR=/tmp
 root=$(pwd)
 out=$root/gpurun_out/profiles_$tag
@@ -33,11 +33,14 @@ profile() {   # name, then the python command line (the program itself follows `
 }
 for c in $cases; do
   case $c in
-    bench)         profile bench bench.py --steps 180 --warmup 5 --no-cpu-baseline ;;
+    # (--no-extra-1024: the 1024^3 trilinear launches of `extra` would share a kernel-stats row with the 512^3 ones)
+    bench)         profile bench bench.py --steps 180 --warmup 5 --no-cpu-baseline --no-extra-1024 ;;
+    linear512)     profile linear512 tools/prof_case.py --size 512 --interp linear --sweep 1 --iters 180 ;;     # BASELINE config #2
     sweep1024)     profile sweep1024 bench.py --size 1024 --steps 60 --warmup 3 --no-cpu-baseline ;;
-    linear1024)    profile linear1024 tools/prof_case.py --size 1024 --interp linear --angle 30 --iters 30 ;;
+    linear1024)    profile linear1024 tools/prof_case.py --size 1024 --interp linear --sweep 6 --iters 30 ;;    # the north star's 1024^3 trilinear sweep
     general512)    profile general512_linear tools/prof_case.py --size 512 --interp linear --general --iters 30
                    profile general512_cubic tools/prof_case.py --size 512 --interp filt_bspline --general --iters 30 ;;
+    prefilter512)  profile prefilter512 tools/prefilter_time.py 512 ;;
     prefilter1024) profile prefilter1024 tools/prefilter_time.py 1024 ;;
   esac
 done
