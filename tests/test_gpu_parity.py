@@ -491,6 +491,19 @@ def test_oneshot_pipeline_ragged_chunks(interp):
     assert np.abs(inout - want).max() <= TOL[interp], interp
 
 
+@pytest.mark.parametrize('interp', ['filt_bspline'])
+def test_oneshot_pipeline_general_matrix(interp):
+    """A general 3-D rotation through the pipelined one-shot call: every output slab waits for the whole (prefiltered) source, the
+    plane-local prefilter passes run per uploaded chunk, the downloads overlap the later slabs' kernels.  Against the oracle and
+    against the plain sequence (VT_NO_MARCH keeps a call off the pipeline)."""
+    shape = (150, 700, 650)                       # 273 MB: above the general-matrix pipeline threshold (256 MiB), ragged chunks
+    vol = rand_vol(shape, 31)
+    for m in (vt.utils.transform_matrix(rotation=(25, -40, 70), rotation_order='sxyz', translation=(1.5, -2.0, 0.25), center=centre(shape)),
+              vt.utils.transform_matrix(rotation=(0, 30, 0), rotation_order='sxyz', center=centre(shape))):      # about axis 1
+        got = vt.affine(vol, m, interpolation=interp, device='gpu')
+        assert np.abs(got - oracle.affine(vol, m, interp)).max() <= TOL[interp], interp
+
+
 @pytest.mark.parametrize('interp', ['linear', 'bspline', 'filt_bspline'])
 def test_output_shape_other_than_source_shape(interp):
     """vt_volume_set_output_shape (scipy's output_shape, transforms.py:136-150): every kernel family with an output grid

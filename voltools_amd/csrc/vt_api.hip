@@ -836,7 +836,7 @@ int create_common(int dev, int D, int H, int W, int interp, const float* data, i
 // copy stream; the transform is launched per output slab on the handle's stream as soon as the last chunk that slab taps
 // has arrived (stream waits on the upload events); every finished slab is downloaded on a second non-blocking copy stream
 // while later chunks are still going up.  The sequence is the one of tools/probes/pipeline_probe.hip (512^3: 12.3 ms
-// against 19.8 ms sequential).  Requirements: an axis-0-separable matrix (each output plane taps a window of source
+// against 19.8 ms sequential).  Axis-0-separable matrices stream (each output plane taps a window of source
 // planes), only the plain resident layout (the secondary copies are built from a complete source).  filt_* interpolations:
 // the X and Y passes of the prefilter are plane-local and run per uploaded chunk; the axis-0 pass already works in chunks
 // of 64 / 128 planes with 16 planes of warm-up, so each of its chunks is launched as soon as those planes are there.  (A
@@ -872,10 +872,15 @@ bool pipeline_eligible(const float* h_volume, int D, int H, int W, int interp, c
     if (is_filtered(interp) && (W > 2048 || prefilter_axis_in_place_ok(1, D, H, W) || prefilter_axis_in_place_ok(0, D, H, W))) return false;
     double m[12];
     for (int i = 0; i < 12; ++i) m[i] = (double)m4x4[i];
-    if (!(m[0] == 1.0 && m[1] == 0.0 && m[2] == 0.0 && m[4] == 0.0 && m[8] == 0.0 && std::fabs(m[3]) < 1.0e9)) return false;
     for (int i = 0; i < 12; ++i)
         if (!std::isfinite(m[i])) return false;
-    return true;
+    // (axis-0-separable matrices stream: an output slab needs a window of source planes.  Any other matrix needs the whole source
+    // before its first output voxel; the pipeline still hides the plane-local prefilter passes behind the uploads and the transform
+    // behind the downloads -- the floor is the two PCIe transfers back to back.  [measured, tools/oneshot_time.py] 512^3 general
+    // rotation: filt_bspline 21.06 -> 20.11 ms, linear 19.76 -> 20.00 (nothing to hide but the chunking's own cost); 250^3 no gain.)
+    const bool separable = m[0] == 1.0 && m[1] == 0.0 && m[2] == 0.0 && m[4] == 0.0 && m[8] == 0.0;
+    if (!separable && !(is_filtered(interp) && n * sizeof(float) >= ((size_t)256 << 20))) return false;
+    return std::fabs(m[3]) < 1.0e9;
 }
 
 // Three streams created back to back: the runtime deals hardware queues to streams round-robin (4 queues), and a
@@ -964,6 +969,7 @@ int oneshot_pipelined(int dev, const float* h_volume, int D, int H, int W, int i
     }
     const double t_uploads = now_ms();
     const int halo = is_cubic(interp) ? 2 : 1;
+    const bool separable = m[0] == 1.0 && m[1] == 0.0 && m[2] == 0.0 && m[4] == 0.0 && m[8] == 0.0;
     const int lflags = (flags | VT_OUT_DEVICE | VT_NO_ZPAIR | VT_NO_QUAD | VT_NO_RSWAP) & ~VT_KEEP_OUTSIDE;
     // Kernel stream, per uploaded chunk: (filt_*) X and Y passes of the prefilter on the chunk's planes (plane-local), then
     // every axis-0 chunk of the prefilter whose input planes (its own + warm-up) are there, then every output slab whose
@@ -995,8 +1001,9 @@ int oneshot_pipelined(int dev, const float* h_volume, int D, int H, int W, int i
         }
         while (next_slab < nslabs) {
             const int d0 = next_slab * Dc, d1 = std::min(D, d0 + Dc);
-            // output plane d taps source planes floor(d + tz) - halo + 1 ... floor(d + tz) + halo
-            const double hi = std::floor((double)(d1 - 1) + m[3]) + halo;
+            // output plane d of an axis-0-separable map taps source planes floor(d + tz) - halo + 1 ... floor(d + tz) + halo; any
+            // other matrix (and the secondary copies its kernels may build) needs every plane
+            const double hi = separable ? std::floor((double)(d1 - 1) + m[3]) + halo : (double)(D - 1);
             if (std::min(hi, (double)(D - 1)) >= (double)final_planes) break;          // wait for more planes
             v->out_plane0 = d0;
             v->oD = d1 - d0;
