@@ -7,7 +7,8 @@
 #include <vector>
 
 // Experiment overrides, read from the environment once per handle (vt_volume_create) -- never on the per-call path.
-// None is needed in production; tools/*.sh and the staging-mode parity test use them to reach planner alternatives.
+// None is needed in production; the A/B runs quoted in DESIGN.md (tools/march_ab.py --env) and a few parity tests use them to reach
+// planner alternatives.  The product build reads 19 of them; the rest belong to the test build (VT_LEGACY) and the ablation build.
 struct Tuning {
     int tile = -1;                 // VT_TILE: force tile configuration (index into the kernel family's table)
     int la = 0;                    // VT_LA: planes / pairs staged ahead by the marching kernels
@@ -38,19 +39,23 @@ struct Tuning {
     {
         auto num = [](const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; };
         tile = num("VT_TILE", -1);
+#ifdef VT_LEGACY              // knobs of round 1's marching kernels: test build only
         la = num("VT_LA", 0);
         march_box = num("VT_MARCH_BOX", -1);
         if (march_box > 1) march_box = 1;
         lxpad = num("VT_LXPAD", -1);
+#endif
         dch = std::max(0, num("VT_DCH", 0));
         blk_h = num("VT_BLK_H", -1);
         blk_w = num("VT_BLK_W", -1);
         plain_tile_order = num("VT_TILE_ORDER", 1) == 0;
         rswap_wfast = num("VT_RSWAP_WFAST", -1);
+#ifdef VT_EXPERIMENTS         // ablation switches: `make EXTRA=-DVT_EXPERIMENTS` only
         exp_nostore = std::getenv("VT_EXP_NOSTORE") != nullptr;
         exp_noload = std::getenv("VT_EXP_NOLOAD") != nullptr;
         exp_nolds = std::getenv("VT_EXP_NOLDS") != nullptr;
         exp_noloop = std::getenv("VT_EXP_NOLOOP") != nullptr;
+#endif
         quad_nt = num("VT_QUAD_NT", -1);
         quad_perm = num("VT_QUAD_PERM", 1);
         quad_zid = num("VT_QUAD_ZID", 1);
