@@ -176,6 +176,28 @@ def test_default_dispatch_uses_tiled_kernel_on_large_volumes(interp):
     assert np.abs(got - oracle.affine(vol, m, interp)).max() <= TOL[interp]
 
 
+@pytest.mark.parametrize('interp', ['linear', 'filt_bspline'])
+def test_secondary_copy_failure_replans_on_the_plain_layout(interp, monkeypatch):
+    """A plane-quad copy that cannot be allocated (here: VT_TEST_FAIL_COPY) must not fail the call nor leave a zero-filled copy
+    behind: the call is planned again without that family and served from the plain layout, every time."""
+    shape = (96, 100, 104)
+    vol = rand_vol(shape, 9)
+    m = MATRICES['rot_inplane45'](shape)
+    want = oracle.affine(vol, m, interp)
+    monkeypatch.setenv('VT_TEST_FAIL_COPY', '1')
+    sv = vt.StaticVolume(vol, interpolation=interp, device='gpu:0')
+    monkeypatch.delenv('VT_TEST_FAIL_COPY')
+    for _ in range(2):                            # the second call must not find a half-built copy either
+        got = sv.affine(m)
+        assert sv.info().last_kernel != 8
+        assert np.abs(got - want).max() <= TOL[interp]
+    sv.close()
+    sv = vt.StaticVolume(vol, interpolation=interp, device='gpu:0')       # the same call with the copy available
+    got = sv.affine(m)
+    assert sv.info().last_kernel == 8 and np.abs(got - want).max() <= TOL[interp]
+    sv.close()
+
+
 @pytest.mark.parametrize('shape', [(1, 1, 1), (1, 5, 7), (5, 5, 5), (2, 3, 130), (130, 3, 2), (13, 1, 64)])
 @pytest.mark.parametrize('interp', ['linear', 'bspline_simple', 'filt_bspline'])
 def test_degenerate_and_ragged_shapes(shape, interp):

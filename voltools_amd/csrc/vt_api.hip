@@ -556,6 +556,7 @@ int ensure_secondary_copy(vt_volume* v, const TilePlan& plan, const AffineParams
 #endif
     } else return 0;
     if (*slot) return 0;
+    if (v->tune.test_fail_copy) return 1;      // VT_TEST_FAIL_COPY: the allocation-failure path, for tests/test_gpu_parity.py
     if (hipMalloc(reinterpret_cast<void**>(slot), bytes) != hipSuccess) {
         (void)hipGetLastError();              // no room for another copy of the volume: a family that reads the plain layout serves the call
         *slot = nullptr;

@@ -25,6 +25,7 @@ struct Tuning {
     int quad_rows = -2;            // VT_QUAD_ROWS: -1 = rows packed back to back, 0..15 = force the row stride S of the bank-aware placement, -2 = planner
     int quad_grid2d = 1;           // VT_QUAD_GRID2D=0: 1-D grid with XCD-contiguous ids over all chunks (round-2 A/B)
     int quad_reverse = -1;         // VT_QUAD_REVERSE: 1 / 0 = the 2-D grid walks the in-plane tiles in descending / ascending order, -1 = planner
+    bool test_fail_copy = false;   // VT_TEST_FAIL_COPY: pretend the secondary resident copies cannot be allocated (the re-planning path)
     int quad_perm = 1;             // VT_QUAD_PERM=0: identity lane -> pixel mapping in the plane-quad kernel (round-3 A/B)
     int quad_zid = 1;              // VT_QUAD_ZID=0: trilinear launches with fz == 0 keep the two-plane kernel (round-3 A/B)
     int zid_dch = 0;               // VT_ZID_DCH: chunk depth of the integer-offset trilinear kernel (0 = the trilinear default)
@@ -57,6 +58,7 @@ struct Tuning {
         exp_noloop = std::getenv("VT_EXP_NOLOOP") != nullptr;
 #endif
         quad_nt = num("VT_QUAD_NT", -1);
+        test_fail_copy = std::getenv("VT_TEST_FAIL_COPY") != nullptr;
         quad_perm = num("VT_QUAD_PERM", 1);
         quad_zid = num("VT_QUAD_ZID", 1);
         zid_dch = num("VT_ZID_DCH", 0);
