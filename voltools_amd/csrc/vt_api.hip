@@ -579,6 +579,7 @@ int ensure_secondary_copy(vt_volume* v, const TilePlan& plan, const AffineParams
         *slot = nullptr;
         return 1;
     }
+    if (std::getenv("VT_DEBUG_ALLOC")) std::fprintf(stderr, "[vt] secondary copy kind %d orientation %d at %p, %zu bytes (plain source %p)\n", plan.kind, ori.quad_idx, (void*)*slot, bytes, (const void*)ori.src_plain);
     if (plan.kind == 8) v->quad_bytes[ori.quad_idx] = bytes;
     else v->P2 = p.sP2;
     return 0;
