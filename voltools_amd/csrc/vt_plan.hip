@@ -365,8 +365,8 @@ bool plan_quad(PlanCtx& c)
     int target_dch = c.cubic ? 64 : (((int64_t)v->H * v->W <= 512 * 512) ? 24 : 32);
     // integer-offset trilinear: no history quad, so short chunks cost only their set-up; [measured, tools/r3_quad_ab.sh zid -> profiles/r03_ab_1_zid.txt] 1024^3: 1.476 ms at
     // 16 planes, 1.509 at 24, 1.518 at 32, 1.568 at 48, 1.595 at 64 (the copy structure alone behaves the same: front_probe);
-    // 512^3: 0.1961 at 24, 0.1979 at 16, 0.1992 at 32
-    if (zid) target_dch = ((int64_t)v->H * v->W > 512 * 512) ? 16 : 20;       // 512^3: 0.1922 at 20, 0.1936 at 24, 0.1953 at 12 (tools/r3_quad_ab.sh depth -> profiles/r03_ab_2_depth.txt)
+    // 512^3 (variants in one process): 0.1961 at 24, 0.1979 at 16, 0.1992 at 32 -- within the handle-to-handle spread; decided per process below
+    if (zid) target_dch = 16;       // 512^3, one process per variant (profiles/r03_process_ab.txt): 0.1896 ms at 16, 0.1911 at 20, 0.1922 at 24, 0.1953 at 32
     if (zid && v->tune.zid_dch > 0) target_dch = v->tune.zid_dch;
     if (v->tune.dch > 0) target_dch = std::max(4, v->tune.dch);
     int64_t nchunks = std::max<int64_t>(1, (v->oD + target_dch - 1) / target_dch);
