@@ -275,11 +275,17 @@ bool quad_pick_tile(PlanCtx& c, int64_t max_stride)
     // configurations in order of preference (first fit wins).  Cubic launches on planes beyond 512^2 prefer the 32 x 32 tile with
     // 512 threads (two pixels per thread as in the 16 x 32 tile, 8 % less halo per voxel): [measured, one process] 1024^3 sweep
     // 1.629 -> 1.603 ms; at 512^3 it wins at the quarter turns only (0.189 vs 0.201 ms) and loses 1-3 % elsewhere.
+    // The integer-offset trilinear kernel prefers the same tile on planes up to 512^2 (large outputs only: half as many workgroups):
+    // [measured, one variant per process, profiles/r03_process_ab.txt] 512^3 sweep 0.1924 -> 0.1876 ms on average (each form is bimodal
+    // by 2 % from process to process), 1024^3 1.471 -> 1.482 (stays on 16 x 32); the cubic kernel at 512^3 loses 3 % with it.
     int order[8], norder = 0;
     const bool big_cubic = c.cubic && (int64_t)v->H * v->W > 512LL * 512;
-    if (big_cubic) order[norder++] = 4;
+    const bool lin_zid = !c.cubic && (float)(c.m[3] - std::floor(c.m[3])) == 0.0f && v->tune.quad_zid != 0;
+    const bool mid_linear = lin_zid && (int64_t)v->H * v->W <= 512LL * 512 && (int64_t)v->oD * v->oH * v->oW >= 384LL * 384 * 384;
+    const bool first4 = big_cubic || mid_linear;
+    if (first4) order[norder++] = 4;
     for (int cfg = 0; cfg < quad_config_count() && norder < 8; ++cfg)
-        if (!(big_cubic && cfg == 4)) order[norder++] = cfg;
+        if (!(first4 && cfg == 4)) order[norder++] = cfg;
     for (int oi = 0; oi < norder; ++oi) {
         const int cfg = order[oi];
         if (v->tune.tile >= 0 && cfg != v->tune.tile) continue;
