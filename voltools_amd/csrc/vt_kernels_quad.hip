@@ -581,6 +581,7 @@ static const QuadCfg kQuad[] = {
     {32, 32, 256},    // 2: four pixels per thread, square tile (least halo per voxel)
     {16, 64, 256},    // 3: four pixels per thread, 256-byte store rows
     {32, 32, 512},    // 4: two pixels per thread, 8 waves
+    {16, 64, 512},    // 5: two pixels per thread, 8 waves, 256-byte store rows
 };
 int quad_max_it() { return kQuadMaxIt; }
 int quad_config_count() { return (int)(sizeof(kQuad) / sizeof(kQuad[0])); }
@@ -603,7 +604,8 @@ static quad_fn quad_entry(int cfg, int kind)
         case 1: return pick_quad<8, 32, 256>(kind);
         case 2: return pick_quad<32, 32, 256>(kind);
         case 3: return pick_quad<16, 64, 256>(kind);
-        default: return pick_quad<32, 32, 512>(kind);
+        case 4: return pick_quad<32, 32, 512>(kind);
+        default: return pick_quad<16, 64, 512>(kind);
     }
 }
 
