@@ -176,6 +176,25 @@ def test_default_dispatch_uses_tiled_kernel_on_large_volumes(interp):
     assert np.abs(got - oracle.affine(vol, m, interp)).max() <= TOL[interp]
 
 
+@pytest.mark.parametrize('tile', ['1', '2', '3', '4', '5'])
+@pytest.mark.parametrize('interp', ['linear', 'bspline'])
+def test_plane_quad_tile_configurations_on_ragged_shapes(interp, tile, monkeypatch):
+    """Every tile configuration of the plane-quad kernel (the planner prefers the 512-thread ones only on 512^3 / 1024^3 launches) on a
+    shape no tile divides: integer and fractional axis-0 offsets (the one- and the two-plane trilinear kernels), angles on both sides of the
+    in-plane transposition, against the oracle."""
+    monkeypatch.setenv('VT_TILE', tile)
+    shape = (41, 70, 150)
+    vol = rand_vol(shape, 13)
+    c = centre(shape)
+    for m in (vt.utils.transform_matrix(rotation=(0, 17, 0), translation=(0.0, 1.5, -2.25), center=c),
+              vt.utils.transform_matrix(rotation=(0, 123, 0), translation=(3.0, -0.5, 0.75), center=c),
+              vt.utils.transform_matrix(rotation=(0, 38, 0), translation=(0.375, 0.0, 0.0), center=c)):
+        got, info = run_case(vol, m, interp, _native.FORCE_TILED)
+        # (a forced configuration whose ring does not fit -- the four-pixel cubic tiles at steep angles -- is served by another family)
+        assert info.last_kernel == 8 or (interp != 'linear' and tile in ('2', '3')), (interp, tile, info.last_kernel)
+        assert np.abs(got - oracle.affine(vol, m, interp)).max() <= TOL[interp], (interp, tile)
+
+
 @pytest.mark.parametrize('interp', ['linear', 'filt_bspline'])
 def test_secondary_copy_failure_replans_on_the_plain_layout(interp, monkeypatch):
     """A plane-quad copy that cannot be allocated (here: VT_TEST_FAIL_COPY) must not fail the call nor leave a zero-filled copy
