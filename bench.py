@@ -230,10 +230,11 @@ def main():
     kernel_ms = kernel_ms_total / args.steps
     algo_bytes = 8.0 * nd * n * n                    # 4 B compulsory source read + 4 B store per output voxel (per rank's launch)
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-    kind_code = {'linear': 0, 'bspline': 1, 'filt_bspline': 1}.get(interp, 2)
+    # (the README sweep has an integer axis-0 offset: trilinear launches run the one-plane instantiation, KIND 3)
+    kind_code = {'linear': 3 if int(info.last_kernel) == 8 else 0, 'bspline': 1, 'filt_bspline': 1}.get(interp, 2)
     kname = {1: f'vt::affine_direct<{kind_code}>', 2: f'vt::affine_tiled<{kind_code}', 3: f'vt::affine_tiled_zsep<{kind_code}',
              4: f'vt::affine_march_zsep<{kind_code}', 5: f'vt::affine_march_zpair<{kind_code}', 8: f'vt::affine_march4<{kind_code}'}.get(int(info.last_kernel), 'vt::affine')
-    case = 'bench' if (n == 512 and interp == 'filt_bspline') else ('sweep1024' if (n == 1024 and interp == 'filt_bspline') else None)
+    case = {(512, 'filt_bspline'): 'bench', (1024, 'filt_bspline'): 'sweep1024', (512, 'linear'): 'linear512', (1024, 'linear'): 'linear1024'}.get((n, interp))
     traffic = measured_traffic('void ' + kname, case) if (case and world == 1) else None
     result = {
         'metric': f'Mvoxels/s, {n}^3 f32 {interp} StaticVolume transform (resident source, device output)',
