@@ -53,7 +53,8 @@ def test_bench_self_launch_ranks_share_one_gpu(world, strong):
 
 def test_bench_forced_slab_path_matches_plain_path():
     """One rank through SlabVolume (a 1-rank RCCL group, the N > 1 code path) against the plain StaticVolume path: same kernel,
-    same launch geometry; kernel time within 10 % (measured: within 2 %, see profiles/)."""
+    same launch geometry; kernel time within 15 % (measured: within 2 %; identical handles of different processes can differ by 5-6 %,
+    profiles/r03_placement_probe.txt)."""
     args = ['--gpus', '1', '--size', '512', '--interp', 'bspline', '--steps', '60', '--warmup', '5', '--prewarm-ms', '100',
             '--no-cpu-baseline', '--no-extra-1024']
     plain = run_bench(args)
@@ -62,4 +63,4 @@ def test_bench_forced_slab_path_matches_plain_path():
     assert plain['config']['kernel'] == slab['config']['kernel'] and plain['config']['tile'] == slab['config']['tile']
     a, b = plain['roofline']['kernel_ms'], slab['roofline']['kernel_ms']
     print(f'plain {a} ms, forced slab {b} ms')
-    assert abs(a - b) <= 0.10 * a
+    assert abs(a - b) <= 0.15 * a
