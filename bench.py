@@ -160,7 +160,13 @@ def main():
     nd = n // world if strong else n               # planes of this rank's slab
     if strong and n % world:
         raise SystemExit('--strong needs size divisible by the number of ranks')
-    vol = np.random.RandomState(rank).random_sample((nd, n, n)).astype(np.float32)
+    if n >= 768:
+        # config #5's slabs (1024^3 each) are generated on the device: 12 GB of host random numbers per rank would be most of the run
+        gen = torch.Generator(device=f'cuda:{local_rank}')
+        gen.manual_seed(rank)
+        vol = torch.rand((nd, n, n), dtype=torch.float32, device=f'cuda:{local_rank}', generator=gen)
+    else:
+        vol = np.random.RandomState(rank).random_sample((nd, n, n)).astype(np.float32)
     use_slab = world > 1 or os.environ.get('BENCH_FORCE_SLAB') == '1'
     if use_slab and dist is None:
         import torch.distributed as dist
@@ -325,7 +331,8 @@ def main():
                                   'algorithmic_bytes': 24.0 * n ** 3, 'kernels': 'prefilter_xy<16,10> (X+Y fused) + prefilter_block<16,18> (Z)'}
         result['extra'] = extra
         if not args.no_cpu_baseline:
-            result['cpu_baseline'] = cpu_baseline(vol, interp, mats[args.warmup:], args.cpu_seconds)
+            host_vol = vol if isinstance(vol, np.ndarray) else vol.cpu().numpy()
+            result['cpu_baseline'] = cpu_baseline(host_vol, interp, mats[args.warmup:], args.cpu_seconds)
 
     sv.close()
     out.free()
