@@ -51,6 +51,16 @@ def test_bench_self_launch_ranks_share_one_gpu(world, strong):
     assert r['roofline']['bound'] == 'hbm' and 0 < r['roofline']['frac'] < 1
 
 
+def test_bench_device_generated_slabs():
+    """Slabs of >= 768^3 (BASELINE config #5 uses 1024^3 per GPU) are generated on the device and handed to SlabVolume as torch tensors:
+    two ranks of 768^3 on the one GPU, weak scaling."""
+    r = run_bench(['--gpus', '2', '--size', '768', '--interp', 'bspline', '--steps', '3', '--warmup', '1', '--prewarm-ms', '0', '--no-cpu-baseline'],
+                  {'BENCH_ONE_GPU': '1'}, timeout=900)
+    assert r['n_gpus'] == 2 and r['scaling'] == 'weak' and r['value'] > 0
+    assert '2 axis-0 slabs of 768x768x768' in r['config']['workload']
+    assert r['halo_exchange']['exchanged_bytes'] == 2 * 768 * 768 * 4 and r['config']['kernel'] == 8
+
+
 def test_bench_forced_slab_path_matches_plain_path():
     """One rank through SlabVolume (a 1-rank RCCL group, the N > 1 code path) against the plain StaticVolume path: same kernel,
     same launch geometry; kernel time within 15 % (measured: within 2 %; identical handles of different processes can differ by 5-6 %,
