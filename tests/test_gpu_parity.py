@@ -124,7 +124,9 @@ def test_marching_staging_modes(interp, box, monkeypatch):
 
 @pytest.mark.parametrize('interp', ['linear', 'filt_bspline'])
 @pytest.mark.parametrize('knob', [{'VT_DCH': '8'}, {'VT_DCH': '64'}, {'VT_LA': '2'}, {'VT_LA': '3'}, {'VT_BLK_H': '3', 'VT_BLK_W': '2'},
-                                  {'VT_BLK_H': '2', 'VT_BLK_W': '5'}])
+                                  {'VT_BLK_H': '2', 'VT_BLK_W': '5'},
+                                  # round 3: lane <-> pixel mapping, row placement in LDS, chunk depth of the one-plane trilinear kernel
+                                  {'VT_QUAD_PERM': '0'}, {'VT_QUAD_ROWS': '-1'}, {'VT_QUAD_ROWS': '5'}, {'VT_ZID_DCH': '8'}, {'VT_QUAD_ZID': '0'}])
 def test_marching_schedule_does_not_change_results(interp, knob, monkeypatch):
     """Chunk depth (incl. the round-aware default), ring depth and tile order are schedules: the marching kernels must return
     the same bits for every one of them (each voxel is summed in one fixed order; the tile SIZE is not such a knob: pixel
