@@ -126,7 +126,9 @@ def test_marching_staging_modes(interp, box, monkeypatch):
 @pytest.mark.parametrize('knob', [{'VT_DCH': '8'}, {'VT_DCH': '64'}, {'VT_LA': '2'}, {'VT_LA': '3'}, {'VT_BLK_H': '3', 'VT_BLK_W': '2'},
                                   {'VT_BLK_H': '2', 'VT_BLK_W': '5'},
                                   # round 3: lane <-> pixel mapping, row placement in LDS, chunk depth of the one-plane trilinear kernel
-                                  {'VT_QUAD_PERM': '0'}, {'VT_QUAD_ROWS': '-1'}, {'VT_QUAD_ROWS': '5'}, {'VT_ZID_DCH': '8'}, {'VT_QUAD_ZID': '0'}])
+                                  {'VT_QUAD_PERM': '0'}, {'VT_QUAD_ROWS': '-1'}, {'VT_QUAD_ROWS': '5'}, {'VT_ZID_DCH': '8'}, {'VT_QUAD_ZID': '0'},
+                                  # chunk layers walked from the last to the first (what every other launch of a handle does)
+                                  {'VT_QUAD_PINGPONG': '2'}, {'VT_QUAD_PINGPONG': '0'}])
 def test_marching_schedule_does_not_change_results(interp, knob, monkeypatch):
     """Chunk depth (incl. the round-aware default), ring depth and tile order are schedules: the marching kernels must return
     the same bits for every one of them (each voxel is summed in one fixed order; the tile SIZE is not such a knob: pixel
@@ -148,6 +150,30 @@ def test_marching_schedule_does_not_change_results(interp, knob, monkeypatch):
             assert info2.last_kernel in kernels
             assert np.array_equal(got, ref), (interp, knob, mname, flags, float(np.abs(got - ref).max()))
             assert np.abs(ref - want).max() <= TOL[interp]
+
+
+@pytest.mark.parametrize('interp', ['linear', 'bspline_simple', 'filt_bspline'])
+def test_alternate_launches_of_a_handle_return_the_same_bits(interp, monkeypatch):
+    """Every other plane-quad launch of a handle walks its chunk layers backwards (the memory-side cache still holds the planes the
+    previous launch read last): a schedule, so launches 1, 2, 3 of one matrix must agree bit for bit, on 8-plane chunks (22 layers)
+    and on the default depth, for integer and fractional axis-0 offsets."""
+    shape = (176, 200, 232)
+    vol = rand_vol(shape, 11)
+    for dch in ('8', None):
+        if dch:
+            monkeypatch.setenv('VT_DCH', dch)
+            monkeypatch.setenv('VT_ZID_DCH', dch)
+        sv = vt.StaticVolume(vol, interpolation=interp, device='gpu:0')
+        for mname in ('rot_inplane45', 'shift_frac'):
+            m = MATRICES[mname](shape)
+            outs = [sv.affine(m) for _ in range(3)]
+            assert sv.info().last_kernel == 8
+            assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]), (interp, dch, mname)
+            assert np.abs(outs[0] - oracle.affine(vol, m, interp)).max() <= TOL[interp]
+        sv.close()
+        if dch:
+            monkeypatch.delenv('VT_DCH')
+            monkeypatch.delenv('VT_ZID_DCH')
 
 
 @pytest.mark.parametrize('interp', ['linear', 'bspline', 'filt_bspline'])

@@ -590,7 +590,13 @@ int launch_planned(vt_volume* v, const TilePlan& plan, const AffineParams& p, co
 {
     if (plan.kind == 8) {
         if (!*ori.quad_slot) return fail(VT_EINVAL, "internal: plane-quad copy missing");
-        VT_HIP(launch_affine_quad(plan.cfg, v->interp, *ori.quad_slot, d_out, p, plan.grid, plan.lds_bytes, v->stream));
+        // Every other launch of a handle walks the chunk layers from the last to the first: the source planes the previous launch
+        // read last are still in the memory-side cache (256 MB, it sees reads and writes alike) when this one starts with them.
+        // A schedule only: each workgroup computes what it computed before.  (VT_QUAD_PINGPONG=0: always first to last; 2: always
+        // last to first -- the control, which measures like 0.)
+        AffineParams q = p;
+        if (v->tune.quad_pingpong == 2 || (v->tune.quad_pingpong == 1 && ((v->launch_no++) & 1))) q.flags |= (1 << 20);
+        VT_HIP(launch_affine_quad(plan.cfg, v->interp, *ori.quad_slot, d_out, q, plan.grid, plan.lds_bytes, v->stream));
 #ifdef VT_LEGACY
     } else if (plan.kind == 5) {
         if (!*ori.pair_slot) return fail(VT_EINVAL, "internal: plane-pair copy missing");

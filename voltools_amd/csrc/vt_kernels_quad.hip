@@ -170,7 +170,7 @@ __global__ __launch_bounds__(NT) void affine_march4(const float* __restrict__ sr
         // 2-D grid: blockIdx.y = chunk, blockIdx.x = in-plane tile.  Workgroups are dispatched x-fastest, so each XCD gets a
         // contiguous band of every chunk layer in turn: the chip works on one or two layers at a time (compact write stream,
         // halos shared inside the band), and the tile decode needs one multiply-high instead of two integer divisions.
-        chunk = blockIdx.y;
+        chunk = (p.flags & (1 << 20)) ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;      // odd launches: layers from the last to the first
         unsigned u = (unsigned)xcd_contiguous(blockIdx.x, gridDim.x);
         if (p.flags & (1 << 30)) u = gridDim.x - 1 - u;             // A/B: tiles walked in descending order
         if (p.flags & (1 << 24)) {                // h fastest (in-plane transposed copy)
@@ -181,7 +181,8 @@ __global__ __launch_bounds__(NT) void affine_march4(const float* __restrict__ sr
             tw_i = (int)u - th_i * p.nTw;
         }
     } else {
-        const int t = xcd_contiguous(blockIdx.x, gridDim.x);
+        int t = xcd_contiguous(blockIdx.x, gridDim.x);
+        if (p.flags & (1 << 20)) t = (int)gridDim.x - 1 - t;
         march_tile(p, t, th_i, tw_i, chunk);
     }
     const int h0 = th_i * TH, w0 = tw_i * TW;
