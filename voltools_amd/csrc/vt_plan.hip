@@ -792,7 +792,13 @@ bool plan_packed(PlanCtx& c, bool have_box, double box_bpv)
     const int64_t pk_tiles = (int64_t)((v->oD + pk.plan.td - 1) / pk.plan.td) * ((v->oH + pk.plan.th - 1) / pk.plan.th) *
                              ((v->oW + pk.plan.tw - 1) / pk.plan.tw);
     const bool enough = pk_tiles >= 6 * (int64_t)v->cu_count * std::max(1, pk.plan.blocks_per_cu);
-    if (!(!have_box || forced || (enough && pk.bpv < (c.cubic ? 0.5 : 0.6) * box_bpv))) return false;
+    // A source that fits the 256 MB memory-side cache is re-read from there, and the box kernel's plainer gather wins unless the
+    // footprint is much smaller than the box; a larger source makes the staged bytes HBM bytes, and the footprint wins whenever
+    // it is smaller at all.  [measured, 100 random rotations, trilinear, ms where the old rule chose boxes: boxes / footprints]
+    // 384^3 (226 MB) 0.211 / 0.220, 512^3 (537 MB) 0.517 / 0.475 (tools/general_tiles.py)
+    const bool beyond_cache = (int64_t)v->D * v->H * v->P * 4 > (256LL << 20);
+    const double margin = c.cubic ? 0.5 : (beyond_cache ? 1.0 : 0.6);
+    if (!(!have_box || forced || (enough && pk.bpv < margin * box_bpv))) return false;
     *c.plan = pk.plan;
     *c.p = pk.p;
     AffineParams* p = c.p;
