@@ -623,6 +623,32 @@ def test_projection_repeated_calls_large_plane(interp):
     sv.close()
 
 
+@pytest.mark.parametrize('interp', ['linear', 'filt_bspline_simple'])
+def test_projection_tilt_series_reuses_the_plane_sum(interp, monkeypatch):
+    """The reference's tilt series (examples/projections.py:20-26: rotation about the projection axis, then sum(axis=0)) asks for
+    the same weighted plane sum at every angle: the handle keeps it and only the 2-D interpolation runs again.  Every projection of
+    the series must equal the oracle's transform-then-sum and the uncached path bit for bit, also after the axis-0 offset or the
+    output depth changed in between (the two things the sum depends on)."""
+    shape = (40, 120, 136)
+    vol = rand_vol(shape, 21)
+    sv = vt.StaticVolume(vol, interpolation=interp, device='gpu:0')
+    series = [(0.0, a) for a in (-60.0, -21.0, 3.0, 45.0)] + [(1.25, 45.0), (1.25, -10.0), (0.0, -10.0), (-2.0, 30.0)]
+    got = []
+    for shift, ang in series:
+        m = vt.utils.transform_matrix(rotation=(ang, 0, 0), rotation_order='sxyz', translation=(shift, 1.0, -2.5), center=centre(shape))
+        got.append(sv.projection(m))
+        assert sv.info().last_kernel == 7
+        want = oracle.affine(vol, m, interp).astype(np.float64).sum(axis=0)
+        assert np.abs(got[-1] - want).max() <= TOL[interp] * shape[0], (interp, shift, ang)
+    sv.close()
+    monkeypatch.setenv('VT_NO_PROJ_CACHE', '1')
+    sv = vt.StaticVolume(vol, interpolation=interp, device='gpu:0')
+    for (shift, ang), g in zip(series, got):
+        m = vt.utils.transform_matrix(rotation=(ang, 0, 0), rotation_order='sxyz', translation=(shift, 1.0, -2.5), center=centre(shape))
+        assert np.array_equal(sv.projection(m), g), (interp, shift, ang)
+    sv.close()
+
+
 @pytest.mark.parametrize('interp', ['linear', 'filt_bspline'])
 def test_full_size_properties_512(interp):
     """BASELINE sizes: properties that need no CPU oracle pass over 134M voxels."""

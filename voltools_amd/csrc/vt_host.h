@@ -115,6 +115,10 @@ struct vt_volume {
     float* d_proj_tmp = nullptr;       // projection of general matrices: the transformed volume before the sum
     size_t proj_tmp_elems = 0;
     vt_volume* proj = nullptr;         // projection helper: 3 x H x W volume [S, S, S] sharing this handle's stream
+    bool proj_sum_valid = false;       // the helper holds the weighted plane sum of (proj_sum_m3, proj_sum_oD, proj_sum_oplane0)
+    double proj_sum_m3 = 0.0;
+    int proj_sum_oD = 0;
+    int64_t proj_sum_oplane0 = 0;
     int edge_pad = 0;                  // VT_EDGE_SCIPY: the resident copy carries this many mirrored voxels on every side (0 = texture contract)
     bool owns_stream = true;
     bool deferred = false;             // created with VT_SRC_DEFERRED: planes still being uploaded, not usable before vt_volume_finalize
