@@ -33,7 +33,7 @@ __device__ __forceinline__ void lds_dma16(const float* g, unsigned lds_addr)
 #pragma clang diagnostic pop
 
 template <int KIND, int TD, int TH, int TW>
-__global__ __launch_bounds__(256) void affine_tiled_packed(const float* __restrict__ src, float* __restrict__ out,
+__global__ __launch_bounds__(256, (KIND == 0 ? 3 : 2)) void affine_tiled_packed(const float* __restrict__ src, float* __restrict__ out,
                                                             const float* __restrict__ zeros16, const AffineParams p,
                                                             const PackGeom geo)
 {
@@ -129,6 +129,50 @@ __global__ __launch_bounds__(256) void affine_tiled_packed(const float* __restri
     // turn the table into what the gather needs: LDS float offset of column 0 of every row
     for (int row = tid; row < rows; row += 256) rowbase[row] = 4 * rowbase[row] - rowx0[row];
     __syncthreads();
+    // Trilinear: the four tap rows of a voxel are rows (z, y), (z, y+1), (z+1, y), (z+1, y+1) of the box.  The table becomes pairs
+    // {byte address of column 0 of row r, of row r + Ly} (it overlays the two int tables: same size), so one 16-byte read at
+    // entry (z, y) returns all four row addresses and a tap pair is one add and one ds_read2_b32 away.
+    int2* const rowpair = reinterpret_cast<int2*>(lds);
+    if constexpr (!CUBIC) {
+        const int buf_b = (int)lds_byte_address(buf);
+        int2 e[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = tid * 4 + r;
+            e[r] = make_int2(0, 0);
+            if (row < rows) {
+                e[r].x = buf_b + 4 * rowbase[row];
+                e[r].y = (row + Ly < rows) ? buf_b + 4 * rowbase[row + Ly] : e[r].x;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = tid * 4 + r;
+            if (row < rows) rowpair[row] = e[r];
+        }
+        __syncthreads();
+    }
+    typedef int pair2 __attribute__((ext_vector_type(4), aligned(8)));
+    typedef float tap2 __attribute__((ext_vector_type(2), aligned(4)));
+    const unsigned rowpair_b = lds_byte_address(lds);
+    // one trilinear sample from the packed image (the order of the seven lerps is the order of every trilinear kernel here)
+    auto sample_linear = [&](int iz, int iy, int ix, float fz, float fy, float fx) -> float {
+        const unsigned ta = rowpair_b + 8u * (unsigned)(__mul24(iz, Ly) + iy);
+        const pair2 t = *reinterpret_cast<const __attribute__((address_space(3))) pair2*>((size_t)ta);      // {r00, r10, r01, r11}
+        const unsigned xo = 4u * (unsigned)ix;
+        const tap2 a00 = *reinterpret_cast<const __attribute__((address_space(3))) tap2*>((size_t)((unsigned)t.x + xo));
+        const tap2 a01 = *reinterpret_cast<const __attribute__((address_space(3))) tap2*>((size_t)((unsigned)t.z + xo));
+        const tap2 a10 = *reinterpret_cast<const __attribute__((address_space(3))) tap2*>((size_t)((unsigned)t.y + xo));
+        const tap2 a11 = *reinterpret_cast<const __attribute__((address_space(3))) tap2*>((size_t)((unsigned)t.w + xo));
+        const float x00 = fmaf(fx, a00.y - a00.x, a00.x);
+        const float x01 = fmaf(fx, a01.y - a01.x, a01.x);
+        const float x10 = fmaf(fx, a10.y - a10.x, a10.x);
+        const float x11 = fmaf(fx, a11.y - a11.x, a11.x);
+        const float y0 = fmaf(fy, x01 - x00, x00);
+        const float y1 = fmaf(fy, x11 - x10, x10);
+        return fmaf(fz, y1 - y0, y0);
+    };
 
     // ---- persistent loop over tiles (XCD-contiguous order) ----
     // Virtual block vb = blockIdx.x + k * gridDim.x plays the role of block vb of a launch with `ntiles` blocks: gridDim.x
@@ -203,6 +247,75 @@ __global__ __launch_bounds__(256) void affine_tiled_packed(const float* __restri
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the direct-to-LDS loads are invisible to hipcc's counters
                 __syncthreads();                                  // drains the direct-to-LDS loads
 
+                // Trilinear tiles wholly inside the output and the valid interval (all but the rim of the volume): no per-voxel
+                // tests, 64-bit coordinate steps (one add each), stores through a buffer descriptor whose scalar offset walks the
+                // planes, four voxels per loop trip so that the table reads, the tap reads and the lerps of neighbouring voxels
+                // interleave.  Same arithmetic, same bits as the loop below.
+                                const bool tile_fast = !CUBIC && !no_lds && all_valid && nd == TD && (h0 + TH <= p.oH) && (w0 + TW <= p.oW) &&
+                                       (int64_t)TD * ostride * 4 < 0x7fffffffLL;
+                if (tile_fast) {
+                    if constexpr (!CUBIC) {
+                        __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+                            reinterpret_cast<char*>(out + ((int64_t)d0 * ostride + (int64_t)h0 * p.oW + w0)), 0, 0x7fffffff, 0x00020000);
+                        const int oplane_b = (int)(ostride * 4);
+                        const uint64_t inc0 = ((uint64_t)(uint32_t)p.inc_hi[0] << 32) | p.inc_lo[0];
+                        const uint64_t inc1 = ((uint64_t)(uint32_t)p.inc_hi[1] << 32) | p.inc_lo[1];
+                        const uint64_t inc2 = ((uint64_t)(uint32_t)p.inc_hi[2] << 32) | p.inc_lo[2];
+#pragma unroll
+                        for (int jj = 0; jj < NJ; ++jj) {
+                            const int j = jh0 + jj * RP;
+                            const Fx f0 = to_fx(fma(p.m[1], (double)j, fma(p.m[2], (double)kw, b[0])));
+                            const Fx f1 = to_fx(fma(p.m[5], (double)j, fma(p.m[6], (double)kw, b[1])));
+                            const Fx f2 = to_fx(fma(p.m[9], (double)j, fma(p.m[10], (double)kw, b[2])));
+                            uint64_t c0 = ((uint64_t)(uint32_t)f0.hi << 32) | f0.lo;
+                            uint64_t c1 = ((uint64_t)(uint32_t)f1.hi << 32) | f1.lo;
+                            uint64_t c2 = ((uint64_t)(uint32_t)f2.hi << 32) | f2.lo;
+                            const int ob = (j * p.oW + kw) * 4;
+                            int soff = 0;
+                            constexpr int U = 2;             // voxels in flight: 4 table reads, then 16 tap reads, then the lerps
+                            static_assert(TD % U == 0, "tile depth");
+                            for (int i = 0; i < TD; i += U) {
+                                unsigned xo[U];
+                                float fz[U], fy[U], fx[U];
+                                pair2 t[U];
+#pragma unroll
+                                for (int u = 0; u < U; ++u) {
+                                    const unsigned ta = rowpair_b + 8u * (unsigned)(__mul24((int)(c0 >> 32), Ly) + (int)(c1 >> 32));
+                                    t[u] = *reinterpret_cast<const __attribute__((address_space(3))) pair2*>((size_t)ta);
+                                    unsigned hx = (unsigned)(c2 >> 32);
+                                    asm("" : "+v"(hx));                       // (one shift of the high word, not a 64-bit funnel shift and a mask)
+                                    xo[u] = hx << 2;
+                                    fz[u] = (float)(unsigned)c0 * 0x1p-32f;
+                                    fy[u] = (float)(unsigned)c1 * 0x1p-32f;
+                                    fx[u] = (float)(unsigned)c2 * 0x1p-32f;
+                                    c0 += inc0; c1 += inc1; c2 += inc2;
+                                }
+                                tap2 a[U][4];
+#pragma unroll
+                                for (int u = 0; u < U; ++u) {
+                                    a[u][0] = *reinterpret_cast<const __attribute__((address_space(3))) tap2*>((size_t)((unsigned)t[u].x + xo[u]));
+                                    a[u][1] = *reinterpret_cast<const __attribute__((address_space(3))) tap2*>((size_t)((unsigned)t[u].z + xo[u]));
+                                    a[u][2] = *reinterpret_cast<const __attribute__((address_space(3))) tap2*>((size_t)((unsigned)t[u].y + xo[u]));
+                                    a[u][3] = *reinterpret_cast<const __attribute__((address_space(3))) tap2*>((size_t)((unsigned)t[u].w + xo[u]));
+                                }
+#pragma unroll
+                                for (int u = 0; u < U; ++u) {
+                                    // (the empty asm statements keep the four x-lerps scalar: packed, they cost six register moves)
+                                    float x00 = fmaf(fx[u], a[u][0].y - a[u][0].x, a[u][0].x); asm("" : "+v"(x00));
+                                    float x01 = fmaf(fx[u], a[u][1].y - a[u][1].x, a[u][1].x); asm("" : "+v"(x01));
+                                    float x10 = fmaf(fx[u], a[u][2].y - a[u][2].x, a[u][2].x); asm("" : "+v"(x10));
+                                    float x11 = fmaf(fx[u], a[u][3].y - a[u][3].x, a[u][3].x); asm("" : "+v"(x11));
+                                    const float y0 = fmaf(fy[u], x01 - x00, x00);
+                                    const float y1 = fmaf(fy[u], x11 - x10, x10);
+                                    const float val = fmaf(fz[u], y1 - y0, y0);
+                                    if (!no_stores || val == 123.456f)
+                                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), orsrc, ob, soff, 0);
+                                    soff += oplane_b;
+                                }
+                            }
+                        }
+                    }
+                } else
 #pragma unroll
                 for (int jj = 0; jj < NJ; ++jj) {
                     const int j = jh0 + jj * RP;
@@ -220,18 +333,7 @@ __global__ __launch_bounds__(256) void affine_tiled_packed(const float* __restri
                         if (no_lds) {
                             val = fz + fy + fx;
                         } else if constexpr (!CUBIC) {
-                            const int* tr = rowbase + (__mul24(iz, Ly) + iy);
-                            const float* r00 = buf + tr[0] + ix;
-                            const float* r01 = buf + tr[1] + ix;
-                            const float* r10 = buf + tr[Ly] + ix;
-                            const float* r11 = buf + tr[Ly + 1] + ix;
-                            const float x00 = fmaf(fx, r00[1] - r00[0], r00[0]);
-                            const float x01 = fmaf(fx, r01[1] - r01[0], r01[0]);
-                            const float x10 = fmaf(fx, r10[1] - r10[0], r10[0]);
-                            const float x11 = fmaf(fx, r11[1] - r11[0], r11[0]);
-                            const float y0 = fmaf(fy, x01 - x00, x00);
-                            const float y1 = fmaf(fy, x11 - x10, x10);
-                            val = fmaf(fz, y1 - y0, y0);
+                            val = sample_linear(iz, iy, ix, fz, fy, fx);
                         } else {
                             float wx[4], wy[4], wz[4];
                             cubic_weights<KIND == 2>(fx, wx);
