@@ -602,14 +602,15 @@ int launch_planned(vt_volume* v, const TilePlan& plan, const AffineParams& p, co
         if (!*ori.pair_slot) return fail(VT_EINVAL, "internal: plane-pair copy missing");
         VT_HIP(launch_affine_zpair(plan.cfg, v->interp, *ori.pair_slot, d_out, p, plan.grid, plan.lds_bytes, v->stream));
 #endif
-    } else if (plan.kind == 9) {
-        if (!v->d_queue) {
+    } else if (plan.kind == 9 || plan.kind == 6) {
+        if (!v->d_queue) {                                           // tile counters of the persistent kernels: zero between launches
             VT_HIP(hipMalloc(reinterpret_cast<void**>(&v->d_queue), 9 * 128));
             VT_HIP(hipMemsetAsync(v->d_queue, 0, 9 * 128, v->stream));
         }
-        VT_HIP(launch_affine_block(plan.cfg, v->interp, v->d_src, d_out, v->d_zeros, v->d_queue, p, plan.geo, plan.grid, plan.lds_bytes, v->stream));
-    } else if (plan.kind == 6) {
-        VT_HIP(launch_affine_packed(plan.cfg, v->interp, v->d_src, d_out, v->d_zeros, p, plan.geo, plan.grid, plan.lds_bytes, v->stream));
+        if (plan.kind == 9)
+            VT_HIP(launch_affine_block(plan.cfg, v->interp, v->d_src, d_out, v->d_zeros, v->d_queue, p, plan.geo, plan.grid, plan.lds_bytes, v->stream));
+        else
+            VT_HIP(launch_affine_packed(plan.cfg, v->interp, v->d_src, d_out, v->d_zeros, v->d_queue, p, plan.geo, plan.grid, plan.lds_bytes, v->stream));
 #ifdef VT_LEGACY
     } else if (plan.kind == 4) {
         VT_HIP(launch_affine_march(plan.cfg, v->interp, ori.src_plain, d_out, p, plan.grid, plan.lds_bytes, v->stream));

@@ -232,7 +232,7 @@ void packed_config(int idx, int* td, int* th, int* tw);
 int packed_rows_max();
 int packed_vectors_max();
 hipError_t init_packed_kernels();
-hipError_t launch_affine_packed(int cfg, int interp, const float* src, float* out, const float* zeros16,
+hipError_t launch_affine_packed(int cfg, int interp, const float* src, float* out, const float* zeros16, int* queue,
                                 const AffineParams& p, const PackGeom& geo, int grid, int lds_bytes, hipStream_t stream);
 int march_rows_max();
 int march_max_it();

@@ -34,8 +34,8 @@ __device__ __forceinline__ void lds_dma16(const float* g, unsigned lds_addr)
 
 template <int KIND, int TD, int TH, int TW>
 __global__ __launch_bounds__(256, (KIND == 0 ? 3 : 2)) void affine_tiled_packed(const float* __restrict__ src, float* __restrict__ out,
-                                                            const float* __restrict__ zeros16, const AffineParams p,
-                                                            const PackGeom geo)
+                                                            const float* __restrict__ zeros16, int* __restrict__ queue,
+                                                            const AffineParams p, const PackGeom geo)
 {
     static_assert(256 % TW == 0 && TH % (256 / TW) == 0, "tile/thread mapping");
     constexpr bool CUBIC = KIND != 0;
@@ -174,16 +174,38 @@ __global__ __launch_bounds__(256, (KIND == 0 ? 3 : 2)) void affine_tiled_packed(
         return fmaf(fz, y1 - y0, y0);
     };
 
-    // ---- persistent loop over tiles (XCD-contiguous order) ----
-    // Virtual block vb = blockIdx.x + k * gridDim.x plays the role of block vb of a launch with `ntiles` blocks: gridDim.x
-    // is a multiple of 8, so vb lands on the same XCD as this workgroup and xcd_contiguous() keeps every XCD on a
-    // contiguous range of tiles.
-    const int nwg = gridDim.x;
-    const int nvirt = (p.flags & (1 << 23)) ? ntiles : blocked_tile_count(p.nTd, p.nTh, p.nTw);
-    for (int vb = blockIdx.x; vb < nvirt; vb += nwg) {
-        const int t = xcd_contiguous(vb, nvirt);
+    // ---- persistent loop over tiles ----
+    // Tiles are handed out from one counter per XCD (blockIdx % 8 is the XCD of a workgroup; every XCD owns a contiguous range of
+    // tile ids, whole 4 x 4 x 4 super-blocks in the blocked order), as in the lane-block kernel: the tiles in flight on an XCD are
+    // always the most recent consecutive ids, a compact patch whose overlapping footprints meet in that XCD's L2, however unevenly
+    // the workgroups progress (tiles outside the volume cost nothing, tiles on its rim more than the others).  With static striding
+    // the patch frays: [measured, 512^3, 100 random rotations] L2 hit rate of the launch 0.35, 2.19 GB of HBM-side traffic.
+    // The next id is fetched while the current tile is gathered; the last workgroup to leave zeroes the counters.
+    int* const ctrl = scratch + 4;                               // (the wave sums of the set-up are dead)
+    const bool plain_order = (p.flags & (1 << 23)) != 0;         // plain (d, h, w) order (VT_TILE_ORDER=0, experiments)
+    const int nids = plain_order ? ntiles : blocked_tile_count(p.nTd, p.nTh, p.nTw);
+    const int xcd = blockIdx.x & 7, per = ((nids >> 6) + 7) / 8 * 64;
+    const int id0 = xcd * per, id_cnt = max(0, min(per, nids - id0));
+    int* const counter = queue + 32 * xcd;
+    const int chunk = p.dch;
+    int nxt = 0;
+    if (tid == 0) nxt = atomicAdd(counter, chunk);
+    int cur = 0, left = 0;
+    for (;;) {
+        if (left == 0) {
+            if (tid == 0) ctrl[0] = nxt;
+            __syncthreads();                                     // the next chunk is visible
+            cur = ctrl[0];
+            left = chunk;
+            __syncthreads();                                     // everyone has read it before thread 0 may overwrite it
+            if (cur >= id_cnt) break;
+            if (tid == 0) nxt = atomicAdd(counter, chunk);
+        }
+        const int t = id0 + cur;
+        ++cur; --left;
+        if (cur > id_cnt) continue;
         int td_i, th_i, tw_i;
-        if (p.flags & (1 << 23)) {                        // plain (d, h, w) order (VT_TILE_ORDER=0, experiments)
+        if (plain_order) {
             tw_i = t % p.nTw;
             const int t2 = t / p.nTw;
             th_i = t2 % p.nTh;
@@ -383,12 +405,19 @@ __global__ __launch_bounds__(256, (KIND == 0 ? 3 : 2)) void affine_tiled_packed(
             }
         }
     }
+    if (tid == 0) {
+        __threadfence();
+        if (atomicAdd(&queue[256], 1) == (int)gridDim.x - 1) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) queue[32 * i] = 0;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
-typedef void (*packed_fn)(const float*, float*, const float*, const AffineParams, const PackGeom);
+typedef void (*packed_fn)(const float*, float*, const float*, int*, const AffineParams, const PackGeom);
 struct PackCfg { int td, th, tw; };
 static const PackCfg kPack[] = {
     {8, 16, 32},
@@ -429,11 +458,11 @@ hipError_t init_packed_kernels()
     return hipSuccess;
 }
 
-hipError_t launch_affine_packed(int cfg, int interp, const float* src, float* out, const float* zeros16,
+hipError_t launch_affine_packed(int cfg, int interp, const float* src, float* out, const float* zeros16, int* queue,
                                 const AffineParams& p, const PackGeom& geo, int grid, int lds_bytes, hipStream_t stream)
 {
     packed_fn fn = packed_entry(cfg, interp_kind(interp));
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds_bytes, stream, src, out, zeros16, p, geo);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds_bytes, stream, src, out, zeros16, queue, p, geo);
     return hipGetLastError();
 }
 

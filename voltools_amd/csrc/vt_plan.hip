@@ -813,6 +813,11 @@ bool plan_packed(PlanCtx& c, bool have_box, double box_bpv)
     int64_t nwg = std::min<int64_t>(ntiles, (int64_t)v->cu_count * std::max(1, c.plan->blocks_per_cu));
     nwg = std::max<int64_t>(8, (nwg + 7) / 8 * 8);
     c.plan->grid = (int)nwg;
+    // One id per fetch: consecutive tiles are neighbours along w, which share source cache lines and complete each other's output
+    // lines; staged by different workgroups at the same time they meet in the L2 ([measured, 512^3 trilinear, 100 random rotations]
+    // 4 ids per fetch: L2 hit 0.22, 2.47 GB of HBM-side traffic; 1: 0.56, 1.54 GB; static striding: 0.35, 2.19 GB).  Making the
+    // output axis that follows source x the fastest one instead of w loses 3 % (the output lines are completed later).
+    p->dch = 1;
     return true;
 }
 
