@@ -1,3 +1,5 @@
+"""Per-matrix time of the trilinear general-matrix kernel on the reference's 100 random rotations, grouped by the output axis along
+which the source x coordinate moves most (the axis whose neighbouring tiles share source cache lines).   python3 tools/axis_group.py"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.getcwd())
