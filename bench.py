@@ -315,6 +315,26 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as e:  # pragma: no cover  (e.g. a smaller device)
                 extra['linear_1024'] = {'error': str(e)}
+        if n == 512:
+            # the reference's own benchmark protocol (tests/benchmark.py:52-54): random `sxyz` rotations about size/2 on the resident
+            # volume, device output -- the general-matrix kernels (lane blocks for cubic, packed footprints for trilinear)
+            rs_g = np.random.RandomState(1)
+            gm = [vt.utils.transform_matrix(rotation=r, rotation_order='sxyz', center=np.divide((n, n, n), 2))
+                  for r in rs_g.uniform(-180, 180, (100, 3))][:40]
+            gen = {'protocol': '40 of the 100 random sxyz rotations of tests/benchmark.py (RandomState(1)), StaticVolume, device output'}
+            for ip_g, handle in ((interp, sv), ('linear', None)):
+                h = handle if handle is not None else vt.StaticVolume(vol, interpolation=ip_g, device=dev)
+                for m_ in gm[:4]:
+                    h.affine(m_, output=out)
+                h.synchronize()
+                h.timer_start()
+                for m_ in gm:
+                    h.affine(m_, output=out)
+                msg = h.timer_stop() / len(gm)
+                gen[ip_g] = {'ms': round(msg, 4), 'frac_of_8TBps': round(algo_bytes / msg / 1e6 / 8000.0, 4), 'kernel': int(h.info().last_kernel)}
+                if handle is None:
+                    h.close()
+            extra['general_rotations'] = gen
         pf_ms = float(info.prefilter_ms)
         if pf_ms > 0:
             # the first prefilter of a process also pays for loading its kernels; a second resident volume shows the
