@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void affine_block(const float* __restrict__
 // ---------------------------------------------------------------------------------------------------
 typedef void (*block_fn)(const float*, float*, const float*, int*, const AffineParams, const PackGeom);
 
-static const int kBlkRS[] = {28, 36};
+static const int kBlkRS[] = {28, 36, 32};        // preference order of the planner
 int block_rs_count() { return (int)(sizeof(kBlkRS) / sizeof(kBlkRS[0])); }
 int block_rs(int idx) { return kBlkRS[idx]; }
 int block_max_vectors() { return 256 * kBlkMaxIt; }
@@ -389,7 +389,7 @@ static block_fn pick_block_kind(int kind)
     }
 }
 
-static block_fn block_entry(int rs_idx, int kind) { return rs_idx == 0 ? pick_block_kind<28>(kind) : pick_block_kind<36>(kind); }
+static block_fn block_entry(int rs_idx, int kind) { return rs_idx == 0 ? pick_block_kind<28>(kind) : (rs_idx == 1 ? pick_block_kind<36>(kind) : pick_block_kind<32>(kind)); }
 
 hipError_t init_block_kernels()
 {

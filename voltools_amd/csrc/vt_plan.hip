@@ -876,23 +876,36 @@ bool plan_block(PlanCtx& c)
         L[r] = (int)std::floor(ext) + 3 + c.halo2;           // floor(hi)-floor(lo) <= floor(ext)+1, +1 upper tap, +1 slack
     }
     const int lx_used = (L[2] + 3 + 3) & ~3;                 // origin aligned down by up to 3, whole vectors
-    int rs_idx = -1;
-    for (int i = 0; i < block_rs_count() && rs_idx < 0; ++i)
-        if (block_rs(i) >= lx_used) rs_idx = i;
-    if (v->tune.block_rs >= 0 && v->tune.block_rs < block_rs_count() && block_rs(v->tune.block_rs) >= lx_used) rs_idx = v->tune.block_rs;
-    if (rs_idx < 0) return false;
-    const int RS = block_rs(rs_idx);
-    // plane stride: the padding (whole vectors, one bank period) with the fewest predicted gather conflicts
-    int best_pad = 0;
-    double best_f = 1e300;
-    for (int pad = 0; pad < 64; pad += 4) {
-        const double f = block_conflicts(m, 0, RS, L[1] * RS + pad, c.cubic) * (1.0 + 0.002 * pad);
-        if (f < best_f - 1e-9) { best_f = f; best_pad = pad; }
+    // Row stride: the smallest of 28 / 36 floats that holds the box row -- or 32 where the box then exceeds the staging budget
+    // (a stride of 32 floats puts rows two apart on the same banks: more conflicts, but 5 of the reference's 100 random rotations
+    // otherwise fall back to the bounding-box kernel at 1.38 instead of ~1.1 ms).  VT_BLOCK_RS forces an index.
+    int rs_idx = -1, RS = 0, PS = 0;
+    int64_t vectors = 0;
+    auto try_rs = [&](int idx) {
+        if (idx < 0 || idx >= block_rs_count() || block_rs(idx) < lx_used) return false;
+        const int rs = block_rs(idx);
+        // plane stride: the padding (whole vectors, one bank period) with the fewest predicted gather conflicts
+        int best_pad = 0;
+        double best_f = 1e300;
+        for (int pad = 0; pad < 64; pad += 4) {
+            if ((int64_t)L[0] * (L[1] * rs + pad) / 4 > block_max_vectors()) break;       // (a padding the staging budget cannot hold)
+            const double f = block_conflicts(m, 0, rs, L[1] * rs + pad, c.cubic) * (1.0 + 0.002 * pad);
+            if (f < best_f - 1e-9) { best_f = f; best_pad = pad; }
+        }
+        if (v->tune.block_pad >= 0) best_pad = v->tune.block_pad & ~3;
+        const int ps = L[1] * rs + best_pad;
+        const int64_t vec = (int64_t)L[0] * ps / 4;
+        if (vec > block_max_vectors()) return false;
+        rs_idx = idx; RS = rs; PS = ps; vectors = vec;
+        return true;
+    };
+    if (v->tune.block_rs >= 0) {
+        if (!try_rs(v->tune.block_rs)) return false;
+    } else {
+        bool ok = false;
+        for (int i = 0; i < block_rs_count() && !ok; ++i) ok = try_rs(i);      // table order = preference order (28, 36, 32)
+        if (!ok) return false;
     }
-    if (v->tune.block_pad >= 0) best_pad = v->tune.block_pad & ~3;
-    const int PS = L[1] * RS + best_pad;
-    const int64_t vectors = (int64_t)L[0] * PS / 4;
-    if (vectors > block_max_vectors()) return false;
     const int64_t plane_b = (int64_t)v->H * v->P * 4;
     if ((int64_t)L[0] * plane_b >= 0x7fffffffLL || (int64_t)T[0] * v->oH * v->oW * 4 >= 0x7fffffffLL) return false;
     const int box_bytes = (int)((vectors + 63) / 64 * 64 * 16);
