@@ -128,7 +128,8 @@ def test_marching_staging_modes(interp, box, monkeypatch):
                                   # round 3: lane <-> pixel mapping, row placement in LDS, chunk depth of the one-plane trilinear kernel
                                   {'VT_QUAD_PERM': '0'}, {'VT_QUAD_ROWS': '-1'}, {'VT_QUAD_ROWS': '5'}, {'VT_ZID_DCH': '8'}, {'VT_QUAD_ZID': '0'},
                                   # chunk layers walked from the last to the first (what every other launch of a handle does)
-                                  {'VT_QUAD_PINGPONG': '2'}, {'VT_QUAD_PINGPONG': '0'}])
+                                  {'VT_QUAD_PINGPONG': '2'}, {'VT_QUAD_PINGPONG': '0'}, {'VT_QUAD_PINGPONG': '2', 'VT_QUAD_GRID2D': '0'},
+                                  {'VT_QUAD_PINGPONG': '2', 'VT_BLK_H': '3', 'VT_BLK_W': '2'}])
 def test_marching_schedule_does_not_change_results(interp, knob, monkeypatch):
     """Chunk depth (incl. the round-aware default), ring depth and tile order are schedules: the marching kernels must return
     the same bits for every one of them (each voxel is summed in one fixed order; the tile SIZE is not such a knob: pixel
