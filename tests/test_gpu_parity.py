@@ -642,7 +642,7 @@ def test_projection_tilt_series_reuses_the_plane_sum(interp, monkeypatch):
         want = oracle.affine(vol, m, interp).astype(np.float64).sum(axis=0)
         assert np.abs(got[-1] - want).max() <= TOL[interp] * shape[0], (interp, shift, ang)
     sv.close()
-    monkeypatch.setenv('VT_NO_PROJ_CACHE', '1')
+    monkeypatch.setenv('VT_NO_PROJ_CACHE', '1')                    # (a handle reads its knobs when it is created)
     sv = vt.StaticVolume(vol, interpolation=interp, device='gpu:0')
     for (shift, ang), g in zip(series, got):
         m = vt.utils.transform_matrix(rotation=(ang, 0, 0), rotation_order='sxyz', translation=(shift, 1.0, -2.5), center=centre(shape))

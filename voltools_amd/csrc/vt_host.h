@@ -27,6 +27,7 @@ struct Tuning {
     int quad_reverse = -1;         // VT_QUAD_REVERSE: 1 / 0 = the 2-D grid walks the in-plane tiles in descending / ascending order, -1 = planner
     bool test_fail_copy = false;   // VT_TEST_FAIL_COPY: pretend the secondary resident copies cannot be allocated (the re-planning path)
     int quad_perm = 1;             // VT_QUAD_PERM=0: identity lane -> pixel mapping in the plane-quad kernel (round-3 A/B)
+    bool no_proj_cache = false;    // VT_NO_PROJ_CACHE: every projection recomputes the weighted plane sum (test of the cache)
     int quad_pingpong = 1;         // VT_QUAD_PINGPONG: 1 = every other launch of a handle walks the chunk layers from the last to the first; 0 / 2 = never / always
     int quad_zid = 1;              // VT_QUAD_ZID=0: trilinear launches with fz == 0 keep the two-plane kernel (round-3 A/B)
     int zid_dch = 0;               // VT_ZID_DCH: chunk depth of the integer-offset trilinear kernel (0 = the trilinear default)
@@ -63,6 +64,7 @@ struct Tuning {
         quad_perm = num("VT_QUAD_PERM", 1);
         quad_zid = num("VT_QUAD_ZID", 1);
         quad_pingpong = num("VT_QUAD_PINGPONG", 1);
+        no_proj_cache = std::getenv("VT_NO_PROJ_CACHE") != nullptr;
         zid_dch = num("VT_ZID_DCH", 0);
         quad_reverse = num("VT_QUAD_REVERSE", -1);
         quad_grid2d = num("VT_QUAD_GRID2D", 1);
