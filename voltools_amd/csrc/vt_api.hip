@@ -115,7 +115,7 @@ float* g_zeros[64];                // 256 bytes of zeros per device: the border 
 // ---------------------------------------------------------------------------------------------------
 // Per-device recycling of what a handle's life costs besides the copies: a HIP stream, two events and small device buffers.
 // A one-shot transform() of a tiny volume spent 0.38 of its 0.43 ms creating and destroying these
-// (tools/oneshot_breakdown.py).  Streams and events go back to a free list when a handle is destroyed (it synchronises
+// (round-1 measurement).  Streams and events go back to a free list when a handle is destroyed (it synchronises
 // first); device buffers up to 64 MiB are kept by exact size, at most 16 of them and 256 MiB in total per device.
 // ---------------------------------------------------------------------------------------------------
 struct DeviceCache {
@@ -133,7 +133,7 @@ struct DeviceCache {
 DeviceCache g_cache[64];
 constexpr size_t kCacheBufMax = (size_t)64 << 20, kCacheTotalMax = (size_t)256 << 20;
 // Large buffers (resident sources, result staging) are recycled too, a few of them: a transfer to or from a device
-// allocation only reaches full PCIe duplex from its third pass on ([measured] tools/duplex_fresh.py: 512 MiB up + down
+// allocation only reaches full PCIe duplex from its third pass on ([measured, round 1] 512 MiB up + down
 // through a buffer from hipMalloc 19.4, 18.0, then 11.7 ms; a buffer allocated per call never gets there), so a one-shot
 // transform() that allocated its buffers per call could not overlap its upload with its download.  With 288 GB of HBM the
 // cache may hold 16 GiB; vt_device_trim releases it.
@@ -292,7 +292,7 @@ struct PinnedScope {
     bool pinned = false;
     // Memory the runtime already knows as pinned host memory (the Python layer's pooled result buffers, a caller's own
     // hipHostMalloc / hipHostRegister): registering the same range a second time SUCCEEDS, and the matching unregister at the
-    // end of the scope then strips the owner's registration ([measured] tools/diag/pin_trace.py: the pool's later
+    // end of the scope then strips the owner's registration ([measured, round 2] the pool's later
     // hipHostUnregister failed with "pointer does not correspond to a registered memory region", and the sticky error
     // failed the next kernel-launch check).
     static bool already_registered(const void* p)
@@ -330,7 +330,7 @@ int run_prefilter(float* d_a, float* d_b, int D, int H, int W, int P, bool lo_in
     float* oth = d_b;
     const int order[3] = {2, 1, 0};
     int first_pass = 0;
-    if (prefilter_xy_ok(D, H, W, P)) {
+    if (prefilter_xy_ok(D, H, W, P, cur, oth)) {
         // X and Y in one launch (vt_kernels_prefilter.hip: prefilter_xy): the plane is read once and written once for both
         VT_HIP(launch_prefilter_xy(cur, oth, D, H, W, P, st));
         float* t = cur; cur = oth; oth = t;
@@ -357,11 +357,13 @@ int run_prefilter(float* d_a, float* d_b, int D, int H, int W, int P, bool lo_in
 // Which resident copy a launch samples, and what is special about its output.
 struct Orientation {
     const float* src_plain = nullptr;  // plain-layout copy the launch (or its pair / quad relayout) is based on
-    float** pair_slot = nullptr;       // where its plane-pair form lives
+#ifdef VT_LEGACY
+    float** pair_slot = nullptr;       // where its plane-pair form lives (test build)
+#endif
     float** quad_slot = nullptr;       // where its plane-quad form lives
     int quad_idx = 0;
     int srcD = 0, srcH = 0;            // depth / height of that copy
-    int pair_W = 0, pair_P = 0;        // row width / pitch of that copy
+    int rowW = 0, rowP = 0;            // row width / pitch of that copy
     bool xswap = false;                // the kernels write an axis-0 <-> 2 exchanged result into d_tmp_x
 };
 
@@ -426,7 +428,10 @@ int try_axis1_exchange(vt_volume* v, const double m[12], int flags, size_t n_out
     *p = ps; *plan = plans;
     p->ostride = v->oW; p->orow = (int64_t)v->oH * v->oW;
     p->ord[0] = 1; p->ord[1] = 0; p->ord[2] = 2;          // original (d, h, w) = this launch's columns (1, 0, 2)
-    ori->src_plain = v->d_src_t; ori->pair_slot = &v->d_src_t_zp; ori->quad_slot = &v->d_src_t_q; ori->quad_idx = 1;
+    ori->src_plain = v->d_src_t; ori->quad_slot = &v->d_src_t_q; ori->quad_idx = 1;
+#ifdef VT_LEGACY
+    ori->pair_slot = &v->d_src_t_zp;
+#endif
     ori->srcD = v->H; ori->srcH = v->D;
     return 0;
 }
@@ -479,8 +484,11 @@ int try_axis2_exchange(vt_volume* v, const double m[12], int flags, size_t n_out
     }
     *p = ps; *plan = plans;
     p->ord[0] = 2; p->ord[1] = 1; p->ord[2] = 0;          // original (d, h, w) = this launch's columns (2, 1, 0)
-    ori->src_plain = v->d_src_x; ori->pair_slot = &v->d_src_x_zp; ori->quad_slot = &v->d_src_x_q; ori->quad_idx = 3;
-    ori->srcD = v->W; ori->srcH = v->H; ori->pair_W = v->D; ori->pair_P = v->Px;
+    ori->src_plain = v->d_src_x; ori->quad_slot = &v->d_src_x_q; ori->quad_idx = 3;
+#ifdef VT_LEGACY
+    ori->pair_slot = &v->d_src_x_zp;
+#endif
+    ori->srcD = v->W; ori->srcH = v->H; ori->rowW = v->D; ori->rowP = v->Px;
     ori->xswap = true;
     return 0;
 }
@@ -518,8 +526,11 @@ int try_inplane_transposed(vt_volume* v, const double m[12], int flags, size_t n
                                   v->Pr, (int64_t)v->W * v->Pr, v->stream));
     }
     *p = ps; *plan = plans;
-    ori->src_plain = v->d_src_r; ori->pair_slot = &v->d_src_r_zp; ori->quad_slot = &v->d_src_r_q; ori->quad_idx = 2;
-    ori->srcD = v->D; ori->srcH = v->W; ori->pair_W = v->H; ori->pair_P = v->Pr;
+    ori->src_plain = v->d_src_r; ori->quad_slot = &v->d_src_r_q; ori->quad_idx = 2;
+#ifdef VT_LEGACY
+    ori->pair_slot = &v->d_src_r_zp;
+#endif
+    ori->srcD = v->D; ori->srcH = v->W; ori->rowW = v->H; ori->rowP = v->Pr;
     // Tile order on the transposed copy: h fastest for the round-1 marching kernels (consecutive tiles read neighbouring source
     // rows); the plane-quad kernel with its 2-D grid keeps w fastest -- [measured, angles 50..130] 1024^3 trilinear 1.58-1.70 ->
     // 1.51-1.63 ms, 1024^3 cubic at 80 / 90 degrees 1.76 / 1.79 -> 1.65 / 1.61, 512^3 equal or better (consecutive tiles complete whole
@@ -556,19 +567,27 @@ int ensure_secondary_copy(vt_volume* v, const TilePlan& plan, const AffineParams
 #endif
     } else return 0;
     if (*slot) return 0;
-    if (v->tune.test_fail_copy) return 1;      // VT_TEST_FAIL_COPY: the allocation-failure path, for tests/test_gpu_parity.py
+#ifdef VT_LEGACY
+    if (v->tune.test_fail_copy) return 1;      // VT_TEST_FAIL_COPY (test build): the allocation-failure path, for tests/test_gpu_parity.py
+#endif
+    // A copy that did not fit is not attempted again at once: a device that is short of memory would pay a volume-sized hipMalloc
+    // (and its failure) on every call.  The next attempt comes kCopyRetryCalls calls later.
+    constexpr int kCopyRetryCalls = 64;
+    int* const retry = (plan.kind == 8) ? &v->copy_retry_in[ori.quad_idx] : nullptr;
+    if (retry && *retry > 0) { --*retry; return 1; }
     if (hipMalloc(reinterpret_cast<void**>(slot), bytes) != hipSuccess) {
         (void)hipGetLastError();              // no room for another copy of the volume: a family that reads the plain layout serves the call
         *slot = nullptr;
+        if (retry) *retry = kCopyRetryCalls;
         return 1;
     }
     hipError_t e = hipMemsetAsync(*slot, 0, bytes, v->stream);       // positions beyond the row's width stay zero
     if (e == hipSuccess) {
         if (plan.kind == 8)
-            e = launch_relayout_zquad(ori.src_plain, *slot, ori.srcD, ori.srcH, ori.pair_W, ori.pair_P, p.sPq, v->stream);
+            e = launch_relayout_zquad(ori.src_plain, *slot, ori.srcD, ori.srcH, ori.rowW, ori.rowP, p.sPq, v->stream);
 #ifdef VT_LEGACY
         else
-            e = launch_relayout_zpair(ori.src_plain, *slot, ori.srcD, ori.srcH, ori.pair_W, ori.pair_P, p.sP2, v->stream);
+            e = launch_relayout_zpair(ori.src_plain, *slot, ori.srcD, ori.srcH, ori.rowW, ori.rowP, p.sP2, v->stream);
 #endif
     }
     if (e != hipSuccess) {
@@ -577,11 +596,14 @@ int ensure_secondary_copy(vt_volume* v, const TilePlan& plan, const AffineParams
         (void)hipFree(*slot);
         (void)hipGetLastError();
         *slot = nullptr;
+        if (retry) *retry = kCopyRetryCalls;
         return 1;
     }
     if (std::getenv("VT_DEBUG_ALLOC")) std::fprintf(stderr, "[vt] secondary copy kind %d orientation %d at %p, %zu bytes (plain source %p)\n", plan.kind, ori.quad_idx, (void*)*slot, bytes, (const void*)ori.src_plain);
     if (plan.kind == 8) v->quad_bytes[ori.quad_idx] = bytes;
+#ifdef VT_LEGACY
     else v->P2 = p.sP2;
+#endif
     return 0;
 }
 
@@ -661,8 +683,11 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
         plan = TilePlan();
         plan.kind = 0;
         ori = Orientation();
-        ori.src_plain = v->d_src; ori.pair_slot = &v->d_src_zp; ori.quad_slot = &v->d_src_q; ori.quad_idx = 0;
-        ori.srcD = v->D; ori.srcH = v->H; ori.pair_W = v->W; ori.pair_P = v->P;
+        ori.src_plain = v->d_src; ori.quad_slot = &v->d_src_q; ori.quad_idx = 0;
+#ifdef VT_LEGACY
+        ori.pair_slot = &v->d_src_zp;
+#endif
+        ori.srcD = v->D; ori.srcH = v->H; ori.rowW = v->W; ori.rowP = v->P;
         const int pf = flags | deny;
         // single-axis rotations about axes 1 / 2 and in-plane maps near a quarter turn march on an exchanged resident copy
         if ((rc = try_axis1_exchange(v, m, pf, n_out, &p, &plan, &ori))) return rc;
@@ -995,7 +1020,7 @@ int oneshot_pipelined(int dev, const float* h_volume, int D, int H, int W, int i
         int final_planes = z1;                     // source planes [0, final_planes) hold what the transform samples
         if (filt) {
             const size_t off = (size_t)z0 * H * v->P;
-            if (prefilter_xy_ok(z1 - z0, H, W, v->P)) {
+            if (prefilter_xy_ok(z1 - z0, H, W, v->P, v->d_src + off, d_tmp + off)) {
                 VT_HIPP(launch_prefilter_xy(v->d_src + off, d_tmp + off, z1 - z0, H, W, v->P, s_k));
             } else {
                 VT_HIPP(launch_prefilter_axis(2, v->d_src + off, v->d_src + off, z1 - z0, H, W, v->P, false, s_k));
@@ -1406,13 +1431,15 @@ int vt_volume_destroy(vt_volume_t* v)
     if (v->stream) hipStreamSynchronize(v->stream);
     if (v->d_src) cached_free(v->dev, v->d_src, v->src_bytes);
     if (v->d_queue) hipFree(v->d_queue);
+#ifdef VT_LEGACY
     if (v->d_src_zp) hipFree(v->d_src_zp);
-    if (v->d_src_t) hipFree(v->d_src_t);
     if (v->d_src_t_zp) hipFree(v->d_src_t_zp);
-    if (v->d_src_x) hipFree(v->d_src_x);
-    if (v->d_src_r) hipFree(v->d_src_r);
     if (v->d_src_r_zp) hipFree(v->d_src_r_zp);
     if (v->d_src_x_zp) hipFree(v->d_src_x_zp);
+#endif
+    if (v->d_src_t) hipFree(v->d_src_t);
+    if (v->d_src_x) hipFree(v->d_src_x);
+    if (v->d_src_r) hipFree(v->d_src_r);
     if (v->d_src_q) hipFree(v->d_src_q);
     if (v->d_src_t_q) hipFree(v->d_src_t_q);
     if (v->d_src_r_q) hipFree(v->d_src_r_q);
@@ -1450,16 +1477,18 @@ int vt_volume_info(const vt_volume_t* v, vt_volume_info_t* info)
     info->last_lds_bytes = v->last_lds_bytes; info->last_grid = v->last_grid;
     info->prefilter_ms = v->prefilter_ms;
     const uint64_t plain = (uint64_t)v->D * v->H * v->P * sizeof(float);
-    info->resident_bytes = plain + (v->d_src_zp ? (uint64_t)((v->D + 1) / 2) * v->H * v->P2 * sizeof(float) : 0) +
-                           (v->d_src_t ? plain : 0) +
-                           (v->d_src_t_zp ? (uint64_t)((v->H + 1) / 2) * v->D * v->P2 * sizeof(float) : 0) +
+    info->resident_bytes = plain + (v->d_src_t ? plain : 0) +
                            (v->proj ? (uint64_t)3 * v->proj->H * v->proj->P * sizeof(float) : 0) +
                            (v->d_src_r ? (uint64_t)v->D * v->W * v->Pr * sizeof(float) : 0) +
-                           (v->d_src_r_zp ? (uint64_t)((v->D + 1) / 2) * v->W * v->P2 * sizeof(float) : 0) +
                            (v->d_src_x ? (uint64_t)v->W * v->H * v->Px * sizeof(float) : 0) +
-                           (v->d_src_x_zp ? (uint64_t)((v->W + 1) / 2) * v->H * v->P2 * sizeof(float) : 0) +
                            (v->d_tmp_x ? (uint64_t)v->tmp_x_elems * sizeof(float) : 0) +
                            v->quad_bytes[0] + v->quad_bytes[1] + v->quad_bytes[2] + v->quad_bytes[3];
+#ifdef VT_LEGACY
+    info->resident_bytes += (v->d_src_zp ? (uint64_t)((v->D + 1) / 2) * v->H * v->P2 * sizeof(float) : 0) +
+                            (v->d_src_t_zp ? (uint64_t)((v->H + 1) / 2) * v->D * v->P2 * sizeof(float) : 0) +
+                            (v->d_src_r_zp ? (uint64_t)((v->D + 1) / 2) * v->W * v->P2 * sizeof(float) : 0) +
+                            (v->d_src_x_zp ? (uint64_t)((v->W + 1) / 2) * v->H * v->P2 * sizeof(float) : 0);
+#endif
     return 0;
 }
 

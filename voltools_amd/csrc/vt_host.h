@@ -8,7 +8,7 @@
 
 // Experiment overrides, read from the environment once per handle (vt_volume_create) -- never on the per-call path.
 // None is needed in production; the A/B runs quoted in DESIGN.md (tools/march_ab.py --env) and a few parity tests use them to reach
-// planner alternatives.  The product build reads 19 of them; the rest belong to the test build (VT_LEGACY) and the ablation build.
+// planner alternatives.  The product build reads 15 of them; the rest belong to the test build (VT_LEGACY) and the ablation build.
 struct Tuning {
     int tile = -1;                 // VT_TILE: force tile configuration (index into the kernel family's table)
     int la = 0;                    // VT_LA: planes / pairs staged ahead by the marching kernels
@@ -60,14 +60,16 @@ struct Tuning {
         exp_noloop = std::getenv("VT_EXP_NOLOOP") != nullptr;
 #endif
         quad_nt = num("VT_QUAD_NT", -1);
+#ifdef VT_LEGACY              // settled A/Bs of round 3 and the allocation-failure hook: test build only (the product build keeps the defaults)
         test_fail_copy = std::getenv("VT_TEST_FAIL_COPY") != nullptr;
         quad_perm = num("VT_QUAD_PERM", 1);
         quad_zid = num("VT_QUAD_ZID", 1);
+        quad_grid2d = num("VT_QUAD_GRID2D", 1);
+#endif
         quad_pingpong = num("VT_QUAD_PINGPONG", 1);
         no_proj_cache = std::getenv("VT_NO_PROJ_CACHE") != nullptr;
         zid_dch = num("VT_ZID_DCH", 0);
         quad_reverse = num("VT_QUAD_REVERSE", -1);
-        quad_grid2d = num("VT_QUAD_GRID2D", 1);
         quad_rows = num("VT_QUAD_ROWS", -2);
         no_block = std::getenv("VT_NO_BLOCK_KERNEL") != nullptr;
         block_rs = num("VT_BLOCK_RS", -1);
@@ -92,14 +94,10 @@ struct vt_volume {
     float* d_src = nullptr;
     size_t src_bytes = 0;              // size of the d_src allocation (small ones are recycled per device)
     float* d_zeros = nullptr;          // 16 bytes of zeros: the border fetch target of the tiled kernel
-    float* d_src_zp = nullptr;         // second resident copy, planes interleaved in pairs (cubic marching kernel); lazy
     float* d_src_t = nullptr;          // resident copy with axes 0 and 1 exchanged (rotations about axis 1 march along it); lazy
-    float* d_src_t_zp = nullptr;       // ... and its plane-pair form; lazy
     float* d_src_r = nullptr;          // resident copy transposed in-plane ([z][x][y], pitch Pr; quarter-turn class of in-plane maps); lazy
-    float* d_src_r_zp = nullptr;       // ... and its plane-pair form; lazy
     int Pr = 0;
     float* d_src_x = nullptr;          // resident copy with axes 0 and 2 exchanged ([x][y][z], pitch Px; rotations about axis 2); lazy
-    float* d_src_x_zp = nullptr;       // ... and its plane-pair form; lazy
     int Px = 0;
     float* d_tmp_x = nullptr;          // exchanged result of an axis-2 launch, before it is turned back
     size_t tmp_x_elems = 0;
@@ -108,7 +106,15 @@ struct vt_volume {
     float* d_src_r_q = nullptr;
     float* d_src_x_q = nullptr;
     size_t quad_bytes[4] = {0, 0, 0, 0};   // allocation sizes of the four quad copies (vt_volume_info)
+    int copy_retry_in[4] = {0, 0, 0, 0};   // calls to go before a quad copy that could not be allocated is attempted again (per orientation)
+#ifdef VT_LEGACY
+    // plane-pair copies of the four orientations (round 1's cubic marching kernel, kind 5): test build only
+    float* d_src_zp = nullptr;
+    float* d_src_t_zp = nullptr;
+    float* d_src_r_zp = nullptr;
+    float* d_src_x_zp = nullptr;
     int P2 = 0;                        // floats per pair-row of d_src_zp
+#endif
     int* d_queue = nullptr;            // lane-block kernel: tile counters (one per XCD + a departure count), zero between launches
     float* d_scratch_out = nullptr;    // staging for host outputs
     double* d_batch_m = nullptr;       // batch launches: n x 12 folded matrices

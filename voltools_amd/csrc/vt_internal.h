@@ -252,7 +252,7 @@ int prefilter_chunk_size(int N);                  // samples per chunk of the st
 int prefilter_warmup();                           // samples of warm-up on each side of a chunk
 hipError_t launch_prefilter_axis0_chunks(const float* src, float* dst, int D, int H, int W, int pitch, int c0, int c1, hipStream_t stream);
 bool prefilter_axis_in_place_ok(int axis, int D, int H, int W);
-bool prefilter_xy_ok(int D, int H, int W, int pitch);
+bool prefilter_xy_ok(int D, int H, int W, int pitch, const void* src, const void* dst);
 hipError_t launch_prefilter_xy(const float* src, float* dst, int D, int H, int W, int pitch, hipStream_t stream);
 
 }  // namespace vt

@@ -18,8 +18,9 @@
 //   * coordinates step in Q32.32 between the eight voxels of a thread (Gray order: one increment per step), output offsets are a
 //     per-thread register plus a per-step scalar.
 // The arithmetic differs from `affine_tiled` only in the association of the 64-term sum (pairs, then x), i.e. by float32
-// rounding of a convex combination; tests hold it to the same tolerance against the oracle.  A non-finite source value reaches
-// every output whose aligned 6-wide x window contains it (two columns more than the 4-tap stencil).
+// rounding of a convex combination; tests hold it to the same tolerance against the oracle.  The columns of the aligned 6-wide window
+// that are not taps are dropped by selects (not by zero weights), so a non-finite source value reaches exactly the outputs whose stencil
+// contains it (tests/test_gpu_ranges.py).
 // Measured limits of the design (profiles/r02_ablate_block_*.txt): staging moves 36 bytes per voxel through
 // the CU's vector-memory path (~70 GB/s per CU from L2); the gather itself is VALU-bound (~120 per 64 voxels).  A variant that
 // staged per-plane footprint rectangles instead of the box (4.6 instead of 8.9 floats per voxel) was correct and slower: its
@@ -53,12 +54,16 @@ __device__ __forceinline__ float cubic_block_sample(unsigned a0, unsigned ps4, i
     cubic_weights<SIMPLE>(fx, wx);
     cubic_weights<SIMPLE>(fy, wy);
     cubic_weights<SIMPLE>(fz, wz);
-    // taps e+par .. e+par+3 of the six values (e .. e+5): weights shifted by the parity; par = 0 re-reads the second pair as
-    // the third (weight 0), so nothing beyond the row's taps is touched
-    const v2f W0 = {par ? 0.f : wx[0], par ? wx[0] : wx[1]};
-    const v2f W1 = {par ? wx[1] : wx[2], par ? wx[2] : wx[3]};
-    const v2f W2 = {par ? wx[3] : 0.f, 0.f};
+    // taps e+par .. e+par+3 of the six values (e .. e+5): picked by the parity at the end; par = 0 re-reads the second pair as
+    // the third, so nothing beyond the row's taps is touched
+#if defined(VT_EXP_BLK)
+    const v2f W0 = {wx[0], wx[1]};
+    const v2f W1 = {wx[2], wx[3]};
+    const v2f W2 = {0.f, 0.f};
+    const unsigned off3 = 8u;
+#else
     const unsigned off3 = par ? 16u : 8u;
+#endif
     unsigned a[4], b[4];
     a[0] = a0; a[1] = a0 + ps4; a[2] = a[1] + ps4; a[3] = a[2] + ps4;
 #pragma unroll
@@ -66,6 +71,21 @@ __device__ __forceinline__ float cubic_block_sample(unsigned a0, unsigned ps4, i
 
     // eight batches of two tap rows (6 reads); two batches in flight
     v2f t[2][6];
+#if defined(VT_EXP_BLK)       // timing experiment (results are wrong for odd columns): the instruction mix of an exact 4-tap gather
+#define VT_BLK_ISSUE(c, h, r)                                                                                                   \
+    lds_read_b64<(2 * h) * RS4>(r[0], a[c]); lds_read_b64<(2 * h) * RS4 + 8>(r[1], a[c]);      \
+    lds_read_b64<(2 * h + 1) * RS4>(r[3], a[c]); lds_read_b64<(2 * h + 1) * RS4 + 8>(r[4], a[c]);
+#define VT_BLK_WAIT(n, r) \
+    asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(r[0]), "+v"(r[1]), "+v"(r[3]), "+v"(r[4]));
+#define VT_BLK_SUM(c, h, r)                                                                       \
+    {                                                                                             \
+        const float w0 = wz[c] * wy[2 * h], w1 = wz[c] * wy[2 * h + 1];                           \
+        S0 = pk_fma(r[0], w0, S0); S1 = pk_fma(r[1], w0, S1);          \
+        S0 = pk_fma(r[3], w1, S0); S1 = pk_fma(r[4], w1, S1);          \
+    }
+#define VT_BLK_N 4
+#else
+#define VT_BLK_N 6
 #define VT_BLK_ISSUE(c, h, r)                                                                                                   \
     lds_read_b64<(2 * h) * RS4>(r[0], a[c]); lds_read_b64<(2 * h) * RS4 + 8>(r[1], a[c]); lds_read_b64<(2 * h) * RS4>(r[2], b[c]);     \
     lds_read_b64<(2 * h + 1) * RS4>(r[3], a[c]); lds_read_b64<(2 * h + 1) * RS4 + 8>(r[4], a[c]); lds_read_b64<(2 * h + 1) * RS4>(r[5], b[c]);
@@ -77,21 +97,35 @@ __device__ __forceinline__ float cubic_block_sample(unsigned a0, unsigned ps4, i
         S0 = pk_fma(r[0], w0, S0); S1 = pk_fma(r[1], w0, S1); S2 = pk_fma(r[2], w0, S2);          \
         S0 = pk_fma(r[3], w1, S0); S1 = pk_fma(r[4], w1, S1); S2 = pk_fma(r[5], w1, S2);          \
     }
+#endif
     v2f S0 = {0.f, 0.f}, S1 = {0.f, 0.f}, S2 = {0.f, 0.f};
+#if defined(VT_EXP_BLK)
+#define VT_BLK_WAITN(r) VT_BLK_WAIT(4, r)
+#else
+#define VT_BLK_WAITN(r) VT_BLK_WAIT(6, r)
+#endif
     VT_BLK_ISSUE(0, 0, t[0])
-    VT_BLK_ISSUE(0, 1, t[1]) VT_BLK_WAIT(6, t[0]) VT_BLK_SUM(0, 0, t[0])
-    VT_BLK_ISSUE(1, 0, t[0]) VT_BLK_WAIT(6, t[1]) VT_BLK_SUM(0, 1, t[1])
-    VT_BLK_ISSUE(1, 1, t[1]) VT_BLK_WAIT(6, t[0]) VT_BLK_SUM(1, 0, t[0])
-    VT_BLK_ISSUE(2, 0, t[0]) VT_BLK_WAIT(6, t[1]) VT_BLK_SUM(1, 1, t[1])
-    VT_BLK_ISSUE(2, 1, t[1]) VT_BLK_WAIT(6, t[0]) VT_BLK_SUM(2, 0, t[0])
-    VT_BLK_ISSUE(3, 0, t[0]) VT_BLK_WAIT(6, t[1]) VT_BLK_SUM(2, 1, t[1])
-    VT_BLK_ISSUE(3, 1, t[1]) VT_BLK_WAIT(6, t[0]) VT_BLK_SUM(3, 0, t[0])
+    VT_BLK_ISSUE(0, 1, t[1]) VT_BLK_WAITN(t[0]) VT_BLK_SUM(0, 0, t[0])
+    VT_BLK_ISSUE(1, 0, t[0]) VT_BLK_WAITN(t[1]) VT_BLK_SUM(0, 1, t[1])
+    VT_BLK_ISSUE(1, 1, t[1]) VT_BLK_WAITN(t[0]) VT_BLK_SUM(1, 0, t[0])
+    VT_BLK_ISSUE(2, 0, t[0]) VT_BLK_WAITN(t[1]) VT_BLK_SUM(1, 1, t[1])
+    VT_BLK_ISSUE(2, 1, t[1]) VT_BLK_WAITN(t[0]) VT_BLK_SUM(2, 0, t[0])
+    VT_BLK_ISSUE(3, 0, t[0]) VT_BLK_WAITN(t[1]) VT_BLK_SUM(2, 1, t[1])
+    VT_BLK_ISSUE(3, 1, t[1]) VT_BLK_WAITN(t[0]) VT_BLK_SUM(3, 0, t[0])
     VT_BLK_WAIT(0, t[1]) VT_BLK_SUM(3, 1, t[1])
+#undef VT_BLK_WAITN
 #undef VT_BLK_ISSUE
 #undef VT_BLK_WAIT
 #undef VT_BLK_SUM
-    const v2f acc = __builtin_elementwise_fma(W0, S0, __builtin_elementwise_fma(W1, S1, W2 * S2));
+#if defined(VT_EXP_BLK)
+    const v2f acc = __builtin_elementwise_fma(W0, S0, W1 * S1);
     return acc.x + acc.y;
+#else
+    // the four columns of the stencil out of the six column sums, by selects: the extra columns of the aligned window never enter
+    // the result (a zero weight would turn a non-finite neighbour into NaN)
+    const float t0 = par ? S0.y : S0.x, t1 = par ? S1.x : S0.y, t2 = par ? S1.y : S1.x, t3 = par ? S2.x : S1.y;
+    return fmaf(wx[3], t3, fmaf(wx[2], t2, fmaf(wx[1], t1, wx[0] * t0)));
+#endif
 }
 
 // Stage the box with per-vector bounds tests (tiles whose box leaves the volume): vectors outside come from a block of zeros.
@@ -302,6 +336,12 @@ __global__ __launch_bounds__(256, 2) void affine_block(const float* __restrict__
             for (int k = 0; k < kBlkMaxIt; ++k)
                 if (k * 256 + wave_first < total)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + 4096 * k), 16, voff[k], 0, 0, 0);
+#if defined(VT_EXP_BLK) && VT_EXP_BLK >= 2        // timing experiment: the staging traffic of a second (parity-shifted) image
+#pragma unroll
+            for (int k = 0; k < kBlkMaxIt; ++k)
+                if (k * 256 + wave_first < total)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + 4096 * k), 16, voff[k], 4, 0, 0);
+#endif
         } else {
             stage_block_checked<RS>(lds, src, zeros16, p, o, total, psv, nvx_used, tid);
         }

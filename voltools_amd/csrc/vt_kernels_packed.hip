@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256, (KIND == 0 ? 3 : 2)) void affine_tiled_packed(
     int* const ctrl = scratch + 4;                               // (the wave sums of the set-up are dead)
     const bool plain_order = (p.flags & (1 << 23)) != 0;         // plain (d, h, w) order (VT_TILE_ORDER=0, experiments)
     const int nids = plain_order ? ntiles : blocked_tile_count(p.nTd, p.nTh, p.nTw);
-    const int xcd = blockIdx.x & 7, per = ((nids >> 6) + 7) / 8 * 64;
+    const int xcd = blockIdx.x & 7, per = (((nids + 63) >> 6) + 7) / 8 * 64;      // ceil: plain order's tile count is no multiple of 64
     const int id0 = xcd * per, id_cnt = max(0, min(per, nids - id0));
     int* const counter = queue + 32 * xcd;
     const int chunk = p.dch;

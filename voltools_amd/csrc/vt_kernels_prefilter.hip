@@ -679,9 +679,11 @@ __global__ __launch_bounds__(64 * NW) void prefilter_xy(const float* __restrict_
 
 // X + Y in one launch where the tile shape pays: rows of >= 64 samples, lines of >= 40; 16-byte aligned rows whose pitch holds whole
 // 8-sample lanes.  Returns false when the shape does not qualify (the caller runs the two passes separately).
-bool prefilter_xy_ok(int D, int H, int W, int pitch)
+bool prefilter_xy_ok(int D, int H, int W, int pitch, const void* src, const void* dst)
 {
     static const bool off = getenv("VT_PF_NO_XY") != nullptr;
+    // (a caller's offset view through vt_prefilter_inplace may be 4-byte aligned only: the separate passes take it)
+    if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) != 0 || src == dst) return false;
     return !off && W >= 64 && H >= 40 && (pitch & 3) == 0 && pitch >= ((W + 7) & ~7) && (int64_t)D * ((H + 127) / 128) * ((W + 479) / 480) < 0x7fffffffLL;
 }
 

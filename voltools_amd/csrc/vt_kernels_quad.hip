@@ -320,13 +320,21 @@ __global__ __launch_bounds__(NT) void affine_march4(const float* __restrict__ sr
                 // Every row start is pinned to a residue c_r = (x0_r + r * S) mod 16, so the gap in front of row r depends on its
                 // predecessor alone: gap_r = (c_r - c_{r-1} - n_{r-1}) mod 16 -- the placement is one more prefix sum, not a walk over
                 // the rows (round 2 walked them with readlane in a scalar loop: ~35 dependent iterations while three waves waited).
-                // Rows in use are contiguous (the footprint is convex); the rows before the first one carry residue 0 and length 0.
+                // Rows in use are usually contiguous (the footprint is convex), but an in-plane minification beyond the stencil's reach
+                // leaves unused box rows between them: the predecessor is the last row IN USE before this one (a max-scan of the
+                // used rows' indices finds it); the rows before the first one carry residue 0 and length 0.
                 const int S = p.row_s;
                 const int c_r = (x0 + lane * S) & 15;
                 const int end_res = (nv > 0) ? ((c_r + nv) & 15) : 0;            // residue of the position right behind this row
-                int prev_end = __shfl_up(end_res, 1);
-                const int prev_nv = __shfl_up(nv, 1);
-                if (lane == 0 || prev_nv == 0) prev_end = 0;                     // first row in use: the image starts at position 0
+                int last_used = (nv > 0) ? lane : -1;
+#pragma unroll
+                for (int s2 = 1; s2 < 64; s2 <<= 1) {
+                    const int up = __shfl_up(last_used, s2);
+                    if (lane >= s2) last_used = max(last_used, up);
+                }
+                const int prev_row = __shfl_up(last_used, 1);                    // last row in use strictly before this one (-1: none)
+                int prev_end = __shfl(end_res, max(prev_row, 0));
+                if (lane == 0 || prev_row < 0) prev_end = 0;                     // first row in use: the image starts at position 0
                 const int gap = (nv > 0) ? ((c_r - prev_end) & 15) : 0;
                 int inc2 = gap + nv;
 #pragma unroll

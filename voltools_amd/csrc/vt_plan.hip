@@ -38,7 +38,7 @@ struct PlanCtx {
 // Chunk count of a marching launch.  Its workgroups all do the same work, so the chip runs them in rounds of `resident`
 // workgroups and a launch of 5.33 rounds takes almost as long as one of 6 ([measured] 512^3 cubic at 0 / 30 degrees:
 // 8 chunks = 5.33 rounds 0.274 / 0.304 ms; 6 chunks = 4.0 rounds 0.261 / 0.296; 3 chunks = 2.0 rounds 0.249 / 0.297;
-// 4 chunks = 2.67 rounds 0.260 / 0.314; tools/dch_rounds.sh).  Among chunk counts from n0/4 to 2*n0 take the one with the
+// 4 chunks = 2.67 rounds 0.260 / 0.314; round-2 measurement).  Among chunk counts from n0/4 to 2*n0 take the one with the
 // least rounds x planes marched per chunk, a partial round charged at its fraction + 0.3; launches of many rounds (>= 16)
 // or of less than one keep n0, and so do planes with more tiles than the chip keeps resident (there deeper chunks
 // separate in-plane neighbours in time and their shared rows miss L2: 640^3 cubic 0.544 vs 0.498 ms).  Used by the pair
