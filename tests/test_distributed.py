@@ -60,6 +60,7 @@ def _worker(rank, world, port, counts, interp, reach, matrices, outdir):
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
+    os.environ['OMP_NUM_THREADS'] = '2' if world <= 3 else '1'
     import torch.distributed as dist
     from oracle import oracle
     from voltools_amd.distributed import SlabVolume, slab_bounds
@@ -107,9 +108,13 @@ def _run(world, counts, interp, reach, matrices, tmp_path):
     mp.spawn(_worker, args=(world, port, counts, interp, reach, matrices, str(tmp_path)), nprocs=world, join=True)
 
 
-@pytest.mark.parametrize('world,counts', [(2, [12, 12]), (3, [9, 7, 8])])
+# (8 ranks: BASELINE config #5's world size -- every interior rank exchanges with both neighbours, and with 20-plane slabs a filt_* halo of
+# 18 planes still comes from the neighbours alone)
+@pytest.mark.parametrize('world,counts', [(2, [12, 12]), (3, [9, 7, 8]), (8, [20] * 8)])
 @pytest.mark.parametrize('interp', ['linear', 'bspline', 'filt_bspline'])
 def test_slab_volume_matches_single_volume(world, counts, interp, tmp_path):
+    if world == 8 and interp == 'linear':
+        pytest.skip('8 ranks: the cubic interpolations only (config #5 is bspline)')
     import voltools_amd as vt
     from oracle import oracle
     G, H, W = sum(counts), 18, 22
@@ -119,7 +124,7 @@ def test_slab_volume_matches_single_volume(world, counts, interp, tmp_path):
                 vt.utils.transform_matrix(rotation=(0, 45, 0), translation=(0, 1.5, -2), center=c),
                 np.eye(4, dtype=np.float32)]
     _run(world, counts, interp, 0, matrices, tmp_path)
-    tol = 2e-6 if not interp.startswith('filt') else 2e-5
+    tol = 1e-6 if not interp.startswith('filt') else 3e-6          # the GPU suite's tolerances (16 planes of prefilter warm-up: |z|^16 = 7e-10)
     for i, m in enumerate(matrices):
         got = np.concatenate([np.load(tmp_path / f'out_{i}_{r}.npy') for r in range(world)])
         want = oracle.affine(vol, m, interp)

@@ -51,6 +51,16 @@ def test_bench_self_launch_ranks_share_one_gpu(world, strong):
     assert r['roofline']['bound'] == 'hbm' and 0 < r['roofline']['frac'] < 1
 
 
+def test_bench_multirank_line_carries_the_cpu_baseline():
+    """North star: "throughput at 1/2/4/8 GPUs reported next to the CPU baseline timed on the same box's host cores" -- the N > 1 line
+    has `cpu_baseline` too (rank 0 times a bounded sample of its slab's workload; the 15 s scipy pass over the whole volume is N = 1 only)."""
+    args = ['--gpus', '2', '--size', '256', '--interp', 'bspline', '--steps', '5', '--warmup', '2', '--prewarm-ms', '0', '--cpu-seconds', '1']
+    r = run_bench(args, {'BENCH_ONE_GPU': '1'})
+    cb = r['cpu_baseline']
+    assert r['n_gpus'] == 2 and cb['value'] > 0 and cb['kind'] == 'port' and cb['cores'] >= 1 and cb['unit'] == 'Mvoxels/s'
+    assert 'scipy_1thread' in cb and 'scipy_1thread_same_workload' not in cb
+
+
 def test_bench_device_generated_slabs():
     """Slabs of >= 768^3 (BASELINE config #5 uses 1024^3 per GPU) are generated on the device and handed to SlabVolume as torch tensors:
     two ranks of 768^3 on the one GPU, weak scaling."""
