@@ -479,7 +479,9 @@ __global__ __launch_bounds__(64 * NW) void prefilter_xy(const float* __restrict_
     constexpr float z1 = kPole, z2 = z1 * z1, z3 = z2 * z1, z4 = z2 * z2, z5 = z4 * z1, z6 = z4 * z2, z7 = z4 * z3, z8 = z4 * z4, z16 = z8 * z8;
     constexpr float zp[9] = {1.0f, z1, z2, z3, z4, z5, z6, z7, z8};
     __shared__ float ends[NW][8][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // (the wave index as a SCALAR: row indices r0 + k and every test on them are then scalar too -- as vector values the compiler kept all
+    // CW of them alive from the loads to the stores and spilled them: 11 scratch dwords per thread, written to HBM like any store)
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // consecutive tiles (the row segments of one plane, then the next plane) go to ONE XCD: the segments of a plane are resident
     // together there and their overlapping warm-up rows meet in that XCD's L2
     int t = xcd_contiguous(blockIdx.x, gridDim.x);
@@ -666,11 +668,16 @@ __global__ __launch_bounds__(64 * NW) void prefilter_xy(const float* __restrict_
     // ---- store rows [ra, rb) x columns [na, nb); behind the line's end the vector is completed with zeros (the pitch padding) ----
     const int nb_st = (nb == W) ? ((W + 3) & ~3) : nb;
     const bool st0 = x0 >= na && x0 < nb_st, st1 = x0 + 4 >= na && x0 + 4 < nb_st;
+    // The row addresses are rebuilt here from one opaque offset: left to itself the compiler forms all CW of them next to the load
+    // addresses at the top of the kernel and keeps them alive to this point -- 11 spilled registers in a 128-register kernel, whose
+    // scratch stores reach HBM like any other store (17 % more bytes written than the tile itself, profiles/r03_prefilter512_summary.json)
+    int64_t roff = (int64_t)r0 * pitch;
+    asm volatile("" : "+v"(roff));
+    float* rp = o + roff;
 #pragma unroll
-    for (int k = 0; k < CW; ++k) {
+    for (int k = 0; k < CW; ++k, rp += pitch) {
         const int pos = r0 + k;
         if (k < cnt && pos >= ra && pos < rb) {
-            float* rp = o + (int64_t)pos * pitch;
             if (st0) *reinterpret_cast<float4*>(rp) = make_float4(v[k][0], v[k][1], v[k][2], v[k][3]);
             if (st1) *reinterpret_cast<float4*>(rp + 4) = make_float4(v[k][4], v[k][5], v[k][6], v[k][7]);
         }

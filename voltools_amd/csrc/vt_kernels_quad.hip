@@ -381,6 +381,14 @@ __global__ __launch_bounds__(NT) void affine_march4(const float* __restrict__ sr
         }
         __syncthreads();                          // the table is dead from here on; the ring may be written
     }
+    // voff[] now holds each vector's offset RELATIVE to the zero vector's: a quad outside the resident copy is staged from the zero
+    // vector by masking that difference (off = zero_off + (voff & mask), mask wave-uniform) -- pure arithmetic.  The obvious form,
+    // `quad_ok ? voff[it] : p.zero_off_q`, selects between two lvalues the nested lambdas below reach through references; the
+    // compiler turned it into a select of two ADDRESSES followed by one load, which kept voff[] in scratch memory in the trilinear
+    // instantiations: 3 dword stores per thread and workgroup, 9 % more bytes written to HBM than the output itself at 16-plane chunks
+    // (WRITE_SIZE 1.088x at 16 planes, 1.044x at 32: profiles/r04_write_size_variants.txt).
+#pragma unroll
+    for (int it = 0; it < kQuadMaxIt; ++it) voff[it] -= p.zero_off_q;
     const int nvec64 = (nvec + 63) & ~63;         // whole waves stage: a wave's instruction is issued in full or not at all
     const int slot_bytes = p.slot_floats * 4;
 
@@ -436,10 +444,11 @@ __global__ __launch_bounds__(NT) void affine_march4(const float* __restrict__ sr
             if (no_loads) return;
             const bool quad_ok = (unsigned)Q < (unsigned)nquads_res;           // wave-uniform
             const int soff = quad_ok ? (Q - Q_base) * quad_bytes : 0;
+            const int okmask = quad_ok ? -1 : 0;
             char* dst = lds_c + slot_off + 16 * wave_first;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                const int off = quad_ok ? voff[it] : p.zero_off_q;
+                const int off = p.zero_off_q + (voff[it] & okmask);
                 if (it + 1 < NIT || last_wave)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + (16 * NT) * it), 16, off, soff, 0, 0);
             }
