@@ -629,8 +629,16 @@ int launch_planned(vt_volume* v, const TilePlan& plan, const AffineParams& p, co
             VT_HIP(hipMalloc(reinterpret_cast<void**>(&v->d_queue), 9 * 128));
             VT_HIP(hipMemsetAsync(v->d_queue, 0, 9 * 128, v->stream));
         }
-        if (plan.kind == 9)
-            VT_HIP(launch_affine_block(plan.cfg, v->interp, v->d_src, d_out, v->d_zeros, v->d_queue, p, plan.geo, plan.grid, plan.lds_bytes, v->stream));
+        if (plan.kind == 9) {
+#ifdef VT_EXPERIMENTS      // occupancy experiment: fewer resident workgroups per CU through a larger LDS request / a smaller persistent grid
+            static const int exp_lds = std::getenv("VT_EXP_BLOCK_LDS") ? std::atoi(std::getenv("VT_EXP_BLOCK_LDS")) : 0;
+            static const int exp_grid = std::getenv("VT_EXP_BLOCK_GRID") ? std::atoi(std::getenv("VT_EXP_BLOCK_GRID")) : 0;
+            VT_HIP(launch_affine_block(plan.cfg, plan.th, v->interp, v->d_src, d_out, v->d_zeros, v->d_queue, p, plan.geo, exp_grid > 0 ? exp_grid : plan.grid,
+                                       std::max(plan.lds_bytes, exp_lds), v->stream));
+#else
+            VT_HIP(launch_affine_block(plan.cfg, plan.th, v->interp, v->d_src, d_out, v->d_zeros, v->d_queue, p, plan.geo, plan.grid, plan.lds_bytes, v->stream));
+#endif
+        }
         else
             VT_HIP(launch_affine_packed(plan.cfg, v->interp, v->d_src, d_out, v->d_zeros, v->d_queue, p, plan.geo, plan.grid, plan.lds_bytes, v->stream));
 #ifdef VT_LEGACY

@@ -222,10 +222,11 @@ hipError_t launch_affine_quad(int cfg, int interp, const float* srcq, float* out
 // lane-block kernel for general matrices (vt_kernels_block.hip)
 int block_rs_count();
 int block_rs(int idx);
-int block_max_vectors();
-void block_tile(int* td, int* th, int* tw);
+int block_rs_order(int th, const int** order);   // row-stride indices in the planner's order of preference for tile height th (16 or 8)
+int block_max_vectors(int th);
+void block_tile(int th, int* td, int* tw);
 hipError_t init_block_kernels();
-hipError_t launch_affine_block(int rs_idx, int interp, const float* src, float* out, const float* zeros16, int* queue,
+hipError_t launch_affine_block(int rs_idx, int th, int interp, const float* src, float* out, const float* zeros16, int* queue,
                                const AffineParams& p, const PackGeom& geo, int grid, int lds_bytes, hipStream_t stream);
 int packed_config_count();
 void packed_config(int idx, int* td, int* th, int* tw);

@@ -34,8 +34,8 @@ namespace vt {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-constexpr int kBlkTD = 8, kBlkTH = 16, kBlkTW = 16;
-constexpr int kBlkMaxIt = 20;                 // staging vectors per thread: boxes up to 5120 vectors = 80 KiB
+constexpr int kBlkTD = 8, kBlkTW = 16;         // tile depth and width; the height is a template parameter: 16 (two workgroups per CU) or 8 (four)
+constexpr int block_max_it(int th) { return th == 16 ? 20 : 10; }      // staging vectors per thread: boxes up to 80 KiB / 40 KiB
 
 template <int OFF>
 __device__ __forceinline__ void lds_read_b64(v2f& r, unsigned a)
@@ -56,14 +56,7 @@ __device__ __forceinline__ float cubic_block_sample(unsigned a0, unsigned ps4, i
     cubic_weights<SIMPLE>(fz, wz);
     // taps e+par .. e+par+3 of the six values (e .. e+5): picked by the parity at the end; par = 0 re-reads the second pair as
     // the third, so nothing beyond the row's taps is touched
-#if defined(VT_EXP_BLK)
-    const v2f W0 = {wx[0], wx[1]};
-    const v2f W1 = {wx[2], wx[3]};
-    const v2f W2 = {0.f, 0.f};
-    const unsigned off3 = 8u;
-#else
     const unsigned off3 = par ? 16u : 8u;
-#endif
     unsigned a[4], b[4];
     a[0] = a0; a[1] = a0 + ps4; a[2] = a[1] + ps4; a[3] = a[2] + ps4;
 #pragma unroll
@@ -71,21 +64,6 @@ __device__ __forceinline__ float cubic_block_sample(unsigned a0, unsigned ps4, i
 
     // eight batches of two tap rows (6 reads); two batches in flight
     v2f t[2][6];
-#if defined(VT_EXP_BLK)       // timing experiment (results are wrong for odd columns): the instruction mix of an exact 4-tap gather
-#define VT_BLK_ISSUE(c, h, r)                                                                                                   \
-    lds_read_b64<(2 * h) * RS4>(r[0], a[c]); lds_read_b64<(2 * h) * RS4 + 8>(r[1], a[c]);      \
-    lds_read_b64<(2 * h + 1) * RS4>(r[3], a[c]); lds_read_b64<(2 * h + 1) * RS4 + 8>(r[4], a[c]);
-#define VT_BLK_WAIT(n, r) \
-    asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(r[0]), "+v"(r[1]), "+v"(r[3]), "+v"(r[4]));
-#define VT_BLK_SUM(c, h, r)                                                                       \
-    {                                                                                             \
-        const float w0 = wz[c] * wy[2 * h], w1 = wz[c] * wy[2 * h + 1];                           \
-        S0 = pk_fma(r[0], w0, S0); S1 = pk_fma(r[1], w0, S1);          \
-        S0 = pk_fma(r[3], w1, S0); S1 = pk_fma(r[4], w1, S1);          \
-    }
-#define VT_BLK_N 4
-#else
-#define VT_BLK_N 6
 #define VT_BLK_ISSUE(c, h, r)                                                                                                   \
     lds_read_b64<(2 * h) * RS4>(r[0], a[c]); lds_read_b64<(2 * h) * RS4 + 8>(r[1], a[c]); lds_read_b64<(2 * h) * RS4>(r[2], b[c]);     \
     lds_read_b64<(2 * h + 1) * RS4>(r[3], a[c]); lds_read_b64<(2 * h + 1) * RS4 + 8>(r[4], a[c]); lds_read_b64<(2 * h + 1) * RS4>(r[5], b[c]);
@@ -97,13 +75,8 @@ __device__ __forceinline__ float cubic_block_sample(unsigned a0, unsigned ps4, i
         S0 = pk_fma(r[0], w0, S0); S1 = pk_fma(r[1], w0, S1); S2 = pk_fma(r[2], w0, S2);          \
         S0 = pk_fma(r[3], w1, S0); S1 = pk_fma(r[4], w1, S1); S2 = pk_fma(r[5], w1, S2);          \
     }
-#endif
     v2f S0 = {0.f, 0.f}, S1 = {0.f, 0.f}, S2 = {0.f, 0.f};
-#if defined(VT_EXP_BLK)
-#define VT_BLK_WAITN(r) VT_BLK_WAIT(4, r)
-#else
 #define VT_BLK_WAITN(r) VT_BLK_WAIT(6, r)
-#endif
     VT_BLK_ISSUE(0, 0, t[0])
     VT_BLK_ISSUE(0, 1, t[1]) VT_BLK_WAITN(t[0]) VT_BLK_SUM(0, 0, t[0])
     VT_BLK_ISSUE(1, 0, t[0]) VT_BLK_WAITN(t[1]) VT_BLK_SUM(0, 1, t[1])
@@ -117,15 +90,10 @@ __device__ __forceinline__ float cubic_block_sample(unsigned a0, unsigned ps4, i
 #undef VT_BLK_ISSUE
 #undef VT_BLK_WAIT
 #undef VT_BLK_SUM
-#if defined(VT_EXP_BLK)
-    const v2f acc = __builtin_elementwise_fma(W0, S0, W1 * S1);
-    return acc.x + acc.y;
-#else
     // the four columns of the stencil out of the six column sums, by selects: the extra columns of the aligned window never enter
     // the result (a zero weight would turn a non-finite neighbour into NaN)
     const float t0 = par ? S0.y : S0.x, t1 = par ? S1.x : S0.y, t2 = par ? S1.y : S1.x, t3 = par ? S2.x : S1.y;
     return fmaf(wx[3], t3, fmaf(wx[2], t2, fmaf(wx[1], t1, wx[0] * t0)));
-#endif
 }
 
 // Stage the box with per-vector bounds tests (tiles whose box leaves the volume): vectors outside come from a block of zeros.
@@ -148,26 +116,33 @@ __device__ __forceinline__ void stage_block_checked(float* lds, const float* __r
     }
 }
 
-template <int KIND, int RS>
-__global__ __launch_bounds__(256, 2) void affine_block(const float* __restrict__ src, float* __restrict__ out,
-                                                        const float* __restrict__ zeros16, int* __restrict__ queue, const AffineParams p,
-                                                        const PackGeom geo)
+// TH = 16: 8 x 16 x 16 tiles, eight voxels per thread, boxes up to 80 KiB, two workgroups per CU (round 2's form).
+// TH = 8 (round 4): 8 x 8 x 16 tiles, four voxels per thread, boxes up to 40 KiB and at most 128 registers: FOUR workgroups per CU.  The
+// kernel's three phases -- tile set-up / voxel arithmetic, staging, LDS gather -- barely overlap inside one workgroup (ablations,
+// profiles/r04_block_ablation.txt: 0.29 + 0.26 + 0.38 ms of a 1.03 ms launch at 512^3, and one workgroup per CU instead of two takes 1.53x
+// as long): what hides a workgroup's staging latency is other workgroups' gathers, and four small ones interleave better than two large.
+template <int KIND, int RS, int TH>
+__device__ __forceinline__ void affine_block_body(const float* __restrict__ src, float* __restrict__ out, const float* __restrict__ zeros16,
+                                                  int* __restrict__ queue, const AffineParams& p, const PackGeom& geo)
 {
     constexpr bool CUBIC = KIND != 0;
     constexpr int HALO = CUBIC ? 1 : 0;
-    constexpr int TD = kBlkTD, TH = kBlkTH, TW = kBlkTW;
+    constexpr int TD = kBlkTD, TW = kBlkTW;
+    constexpr int NS = TH == 16 ? 8 : 4;                             // voxels per thread
+    constexpr int kBlkMaxIt = block_max_it(TH);
+    constexpr bool PIN = TH == 16;                                   // launch constants pinned in vector registers (plenty at 2 workgroups per CU)
     constexpr int nvx = RS / 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wave_first = __builtin_amdgcn_readfirstlane(tid & ~63);
     // a wave is a 4 x 4 x 4 block of voxels (32-lane groups 2 x 4 x 4), the workgroup 4 x 8 x 8; the eight voxels of a thread in
-    // Gray order: w+8, h+8, w-8, d+4, w+8, h-8, w-8
+    // Gray order: w+8, h+8, w-8, d+4, w+8, h-8, w-8 (TH = 16), the four of the half-height tile: w+8, d+4, w-8
     const int vd = lane >> 4, vh = 4 * (wv >> 1) + ((lane >> 2) & 3), vw = 4 * (wv & 1) + (lane & 3);
-    constexpr int sd[8] = {0, 0, 0, 0, 4, 4, 4, 4};
-    constexpr int sh[8] = {0, 0, 8, 8, 8, 8, 0, 0};
+    constexpr int sd[8] = {0, 0, TH == 16 ? 0 : 4, TH == 16 ? 0 : 4, 4, 4, 4, 4};
+    constexpr int sh[8] = {0, 0, TH == 16 ? 8 : 0, TH == 16 ? 8 : 0, 8, 8, 0, 0};
     constexpr int sw[8] = {0, 8, 8, 0, 0, 8, 8, 0};
-    constexpr int which[7] = {0, 1, 2, 3, 0, 4, 2};              // increments: +w8, +h8, -w8, +d4, -h8
+    constexpr int which[7] = {0, TH == 16 ? 1 : 3, 2, 3, 0, 4, 2};              // increments: 0 = +w8, 1 = +h8, 2 = -w8, 3 = +d4, 4 = -h8
 
     const int Lz = p.Lz, Ly = p.Ly, ps = p.Lps;
     const int psv = ps >> 2;
@@ -212,16 +187,16 @@ __global__ __launch_bounds__(256, 2) void affine_block(const float* __restrict__
         for (int r = 0; r < 3; ++r) {
             inc_hi[k][r] = p.binc_hi[k][r];
             inc_lo[k][r] = p.binc_lo[k][r];
-            asm volatile("" : "+v"(inc_hi[k][r]), "+v"(inc_lo[k][r]));
+            if constexpr (PIN) asm volatile("" : "+v"(inc_hi[k][r]), "+v"(inc_lo[k][r]));
         }
     // ... and so do the float64 constants of the tile geometry (float64 arithmetic is vector arithmetic anyway)
     double gm[12], gneg[3], gpos[3], gvlo[3], gvhi[3];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) { gm[i] = p.m[i]; asm volatile("" : "+v"(gm[i])); }
+    for (int i = 0; i < 12; ++i) { gm[i] = p.m[i]; if constexpr (PIN) asm volatile("" : "+v"(gm[i])); }
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         gneg[r] = p.neg[r]; gpos[r] = p.pos[r]; gvlo[r] = p.vlo[r]; gvhi[r] = p.vhi[r];
-        asm volatile("" : "+v"(gneg[r]), "+v"(gpos[r]), "+v"(gvlo[r]), "+v"(gvhi[r]));
+        if constexpr (PIN) asm volatile("" : "+v"(gneg[r]), "+v"(gpos[r]), "+v"(gvlo[r]), "+v"(gvhi[r]));
     }
     // canonical_inside (vt_device.h) on the register copies of the matrix: the same float64 chain in the original problem's column order
     const int oc0 = p.ord[0], oc1 = p.ord[1], oc2 = p.ord[2];
@@ -231,8 +206,11 @@ __global__ __launch_bounds__(256, 2) void affine_block(const float* __restrict__
         mp[r][0] = oc0 == 0 ? p.m[4 * r] : (oc0 == 1 ? p.m[4 * r + 1] : p.m[4 * r + 2]);
         mp[r][1] = oc1 == 0 ? p.m[4 * r] : (oc1 == 1 ? p.m[4 * r + 1] : p.m[4 * r + 2]);
         mp[r][2] = oc2 == 0 ? p.m[4 * r] : (oc2 == 1 ? p.m[4 * r + 1] : p.m[4 * r + 2]);
-        asm volatile("" : "+v"(mp[r][0]), "+v"(mp[r][1]), "+v"(mp[r][2]));
+        if constexpr (PIN) asm volatile("" : "+v"(mp[r][0]), "+v"(mp[r][1]), "+v"(mp[r][2]));
     }
+    double toff[3];                                               // M.(vd, vh, vw): this thread's first voxel relative to the tile's
+#pragma unroll
+    for (int r = 0; r < 3; ++r) toff[r] = fma(p.m[4 * r], (double)vd, fma(p.m[4 * r + 1], (double)vh, p.m[4 * r + 2] * (double)vw));
     auto inside_canonical = [&](int d, int h, int w) {
         const double x0 = (double)(oc0 == 0 ? d : (oc0 == 1 ? h : w));
         const double x1 = (double)(oc1 == 0 ? d : (oc1 == 1 ? h : w));
@@ -311,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void affine_block(const float* __restrict__
             // the whole tile maps outside the valid interval: zero-fill (or leave untouched)
             if (!keep) {
 #pragma unroll
-                for (int s = 0; s < 8; ++s) {
+                for (int s = 0; s < NS; ++s) {
                     const int d = d0 + vd + sd[s], h = h0 + vh + sh[s], w = w0 + vw + sw[s];
                     if (whole || (d < p.oD && h < p.oH && w < p.oW))
                         __builtin_amdgcn_raw_buffer_store_b32(0u, orsrc, obase, (sd[s] >> 2) * ostep_d + (sh[s] >> 3) * ostep_h + 4 * sw[s], 0);
@@ -336,27 +314,21 @@ __global__ __launch_bounds__(256, 2) void affine_block(const float* __restrict__
             for (int k = 0; k < kBlkMaxIt; ++k)
                 if (k * 256 + wave_first < total)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + 4096 * k), 16, voff[k], 0, 0, 0);
-#if defined(VT_EXP_BLK) && VT_EXP_BLK >= 2        // timing experiment: the staging traffic of a second (parity-shifted) image
-#pragma unroll
-            for (int k = 0; k < kBlkMaxIt; ++k)
-                if (k * 256 + wave_first < total)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + 4096 * k), 16, voff[k], 4, 0, 0);
-#endif
         } else {
             stage_block_checked<RS>(lds, src, zeros16, p, o, total, psv, nvx_used, tid);
         }
-        // this thread's first voxel, box coordinates in Q32.32 (while the loads are in flight)
+        // this thread's first voxel, box coordinates in Q32.32 (while the loads are in flight): the tile's base plus the thread's own
+        // offset M.(vd, vh, vw), which is formed once per launch
         Fx c[3];
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
-            c[r] = to_fx(fma(gm[4 * r], (double)vd, fma(gm[4 * r + 1], (double)vh, fma(gm[4 * r + 2], (double)vw, base[r] - (double)o[r]))));
+        for (int r = 0; r < 3; ++r) c[r] = to_fx((base[r] - (double)o[r]) + toff[r]);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
         // ---- gather ----
         const bool fast = all_valid && whole;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
+        for (int s = 0; s < NS; ++s) {
             float val;
             if (no_lds) {
                 val = fx_frac(c[0]) + fx_frac(c[1]) + fx_frac(c[2]);
@@ -392,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void affine_block(const float* __restrict__
                     else if (!keep) __builtin_amdgcn_raw_buffer_store_b32(0u, orsrc, obase, soff, 0);
                 }
             }
-            if (s < 7) {
+            if (s < NS - 1) {
 #pragma unroll
                 for (int r = 0; r < 3; ++r) fx_step(c[r], inc_hi[which[s]][r], inc_lo[which[s]][r]);
             }
@@ -408,44 +380,86 @@ __global__ __launch_bounds__(256, 2) void affine_block(const float* __restrict__
     }
 }
 
+// the two kernels: one body, two register / occupancy budgets (the second argument of __launch_bounds__ is waves per SIMD: 2 or 4
+// workgroups of 256 threads per CU).  (Two entry points rather than a tile-height template parameter in the attribute: with a
+// value-dependent __launch_bounds__ hipcc 7.2 emitted no host stub for kernels whose address is only taken through a function pointer.)
+template <int KIND, int RS>
+__global__ __launch_bounds__(256, 2) void affine_block(const float* __restrict__ src, float* __restrict__ out, const float* __restrict__ zeros16,
+                                                        int* __restrict__ queue, const AffineParams p, const PackGeom geo)
+{
+    affine_block_body<KIND, RS, 16>(src, out, zeros16, queue, p, geo);
+}
+template <int KIND, int RS>
+__global__ __launch_bounds__(256, 4) void affine_block_half(const float* __restrict__ src, float* __restrict__ out, const float* __restrict__ zeros16,
+                                                             int* __restrict__ queue, const AffineParams p, const PackGeom geo)
+{
+    affine_block_body<KIND, RS, 8>(src, out, zeros16, queue, p, geo);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
 typedef void (*block_fn)(const float*, float*, const float*, int*, const AffineParams, const PackGeom);
 
-static const int kBlkRS[] = {28, 36, 32};        // preference order of the planner
+// row strides (floats).  Odd multiples of 4 are the bank-friendly ones (rows 8 apart share a bank pair); 16 / 24 / 32 serve boxes that
+// exceed the staging budget at the next friendly stride.  The planner walks block_rs_order(th): 28, 36, 32 for the full-height tile (round
+// 2's choice), every stride in order of preference for the half-height one.
+static const int kBlkRS[] = {28, 36, 32, 12, 20, 16, 24};
+static const int kOrder16[] = {0, 1, 2};
+static const int kOrder8[] = {3, 4, 0, 1, 5, 6, 2};
 int block_rs_count() { return (int)(sizeof(kBlkRS) / sizeof(kBlkRS[0])); }
 int block_rs(int idx) { return kBlkRS[idx]; }
-int block_max_vectors() { return 256 * kBlkMaxIt; }
-void block_tile(int* td, int* th, int* tw) { *td = kBlkTD; *th = kBlkTH; *tw = kBlkTW; }
+int block_rs_order(int th, const int** order) { *order = th == 16 ? kOrder16 : kOrder8; return th == 16 ? 3 : 7; }
+int block_max_vectors(int th) { return 256 * block_max_it(th); }
+void block_tile(int th, int* td, int* tw) { (void)th; *td = kBlkTD; *tw = kBlkTW; }
 
-template <int RS>
+template <int RS, int TH>
 static block_fn pick_block_kind(int kind)
 {
+    if (TH == 16) {
+        switch (kind) {
+            case 0: return affine_block<0, RS>;
+            case 1: return affine_block<1, RS>;
+            default: return affine_block<2, RS>;
+        }
+    }
     switch (kind) {
-        case 0: return affine_block<0, RS>;
-        case 1: return affine_block<1, RS>;
-        default: return affine_block<2, RS>;
+        case 0: return affine_block_half<0, RS>;
+        case 1: return affine_block_half<1, RS>;
+        default: return affine_block_half<2, RS>;
     }
 }
 
-static block_fn block_entry(int rs_idx, int kind) { return rs_idx == 0 ? pick_block_kind<28>(kind) : (rs_idx == 1 ? pick_block_kind<36>(kind) : pick_block_kind<32>(kind)); }
+static block_fn block_entry(int rs_idx, int kind, int th)
+{
+    if (th == 16) return rs_idx == 0 ? pick_block_kind<28, 16>(kind) : (rs_idx == 1 ? pick_block_kind<36, 16>(kind) : pick_block_kind<32, 16>(kind));
+    switch (rs_idx) {
+        case 0: return pick_block_kind<28, 8>(kind);
+        case 1: return pick_block_kind<36, 8>(kind);
+        case 2: return pick_block_kind<32, 8>(kind);
+        case 3: return pick_block_kind<12, 8>(kind);
+        case 4: return pick_block_kind<20, 8>(kind);
+        case 5: return pick_block_kind<16, 8>(kind);
+        default: return pick_block_kind<24, 8>(kind);
+    }
+}
 
 hipError_t init_block_kernels()
 {
-    for (int rs = 0; rs < block_rs_count(); ++rs)
-        for (int kind = 0; kind < 3; ++kind) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(block_entry(rs, kind)),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-        }
+    for (int th = 8; th <= 16; th += 8)
+        for (int rs = 0; rs < (th == 16 ? 3 : block_rs_count()); ++rs)
+            for (int kind = 0; kind < 3; ++kind) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(block_entry(rs, kind, th)),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return e;
+            }
     return hipSuccess;
 }
 
-hipError_t launch_affine_block(int rs_idx, int interp, const float* src, float* out, const float* zeros16, int* queue,
+hipError_t launch_affine_block(int rs_idx, int th, int interp, const float* src, float* out, const float* zeros16, int* queue,
                                const AffineParams& p, const PackGeom& geo, int grid, int lds_bytes, hipStream_t stream)
 {
-    hipLaunchKernelGGL(block_entry(rs_idx, interp_kind(interp)), dim3(grid), dim3(256), lds_bytes, stream, src, out, zeros16, queue, p, geo);
+    hipLaunchKernelGGL(block_entry(rs_idx, interp_kind(interp), th), dim3(grid), dim3(256), lds_bytes, stream, src, out, zeros16, queue, p, geo);
     return hipGetLastError();
 }
 

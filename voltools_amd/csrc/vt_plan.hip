@@ -851,7 +851,16 @@ double block_conflicts(const double m[12], int lm, int RS, int PS, bool cubic)
     return tot / 4.0;
 }
 
+bool plan_block_th(PlanCtx& c, int th);
+
+// the half-height tile first where it is asked for (its box must fit 40 KiB), else round 2's full-height tile
 bool plan_block(PlanCtx& c)
+{
+    if (c.v->tune.block_th == 8 && plan_block_th(c, 8)) return true;
+    return plan_block_th(c, 16);
+}
+
+bool plan_block_th(PlanCtx& c, int th)
 {
     const vt_volume* v = c.v;
     const double* m = c.m;
@@ -866,8 +875,10 @@ bool plan_block(PlanCtx& c)
     // 200^3 0.112 / 0.090, 250^3 0.158 / 0.161, 288^3 0.212 / 0.223, 384^3 0.473 / 0.553, 512^3 1.05 / 1.23, 640^3 2.10 / 2.62
     // (tools/general_ab.py, VT_BLOCK_MIN)
     if (!(c.flags & VT_FORCE_TILED) && (int64_t)v->oD * v->oH * v->oW < (int64_t)v->tune.block_min * v->tune.block_min * v->tune.block_min) return false;
+    // tile height 8 (8 x 8 x 16 voxels, boxes of at most 40 KiB, four workgroups per CU) or 16 (round 2's 8 x 16 x 16, two per CU)
     int T[3];
-    block_tile(&T[0], &T[1], &T[2]);
+    T[1] = th;
+    block_tile(th, &T[0], &T[2]);
     int L[3];
     for (int r = 0; r < 3; ++r) {
         double ext = 0;
@@ -882,28 +893,30 @@ bool plan_block(PlanCtx& c)
     int rs_idx = -1, RS = 0, PS = 0;
     int64_t vectors = 0;
     auto try_rs = [&](int idx) {
-        if (idx < 0 || idx >= block_rs_count() || block_rs(idx) < lx_used) return false;
+        if (idx < 0 || idx >= block_rs_count() || (th == 16 && idx > 2) || block_rs(idx) < lx_used) return false;
         const int rs = block_rs(idx);
         // plane stride: the padding (whole vectors, one bank period) with the fewest predicted gather conflicts
         int best_pad = 0;
         double best_f = 1e300;
         for (int pad = 0; pad < 64; pad += 4) {
-            if ((int64_t)L[0] * (L[1] * rs + pad) / 4 > block_max_vectors()) break;       // (a padding the staging budget cannot hold)
+            if ((int64_t)L[0] * (L[1] * rs + pad) / 4 > block_max_vectors(th)) break;       // (a padding the staging budget cannot hold)
             const double f = block_conflicts(m, 0, rs, L[1] * rs + pad, c.cubic) * (1.0 + 0.002 * pad);
             if (f < best_f - 1e-9) { best_f = f; best_pad = pad; }
         }
         if (v->tune.block_pad >= 0) best_pad = v->tune.block_pad & ~3;
         const int ps = L[1] * rs + best_pad;
         const int64_t vec = (int64_t)L[0] * ps / 4;
-        if (vec > block_max_vectors()) return false;
+        if (vec > block_max_vectors(th)) return false;
         rs_idx = idx; RS = rs; PS = ps; vectors = vec;
         return true;
     };
     if (v->tune.block_rs >= 0) {
         if (!try_rs(v->tune.block_rs)) return false;
     } else {
+        const int* order = nullptr;
+        const int norder = block_rs_order(th, &order);                          // the tile height's order of preference
         bool ok = false;
-        for (int i = 0; i < block_rs_count() && !ok; ++i) ok = try_rs(i);      // table order = preference order (28, 36, 32)
+        for (int i = 0; i < norder && !ok; ++i) ok = try_rs(order[i]);
         if (!ok) return false;
     }
     const int64_t plane_b = (int64_t)v->H * v->P * 4;
@@ -960,7 +973,7 @@ bool plan_block(PlanCtx& c)
             if (lo >= 4294967296.0) { lo = 0; hi += 1; }
             p->binc_hi[s][r] = hi; p->binc_lo[s][r] = (uint32_t)lo;
         }
-    plan->blocks_per_cu = (int)std::min<int64_t>(2, (160 * 1024) / lds_bytes);
+    plan->blocks_per_cu = (int)std::min<int64_t>(th == 16 ? 2 : 4, (160 * 1024) / lds_bytes);
     const int64_t ids = blocked_tile_count(p->nTd, p->nTh, p->nTw);
     int64_t grid = std::min<int64_t>((int64_t)v->cu_count * plan->blocks_per_cu, ids);
     grid = std::max<int64_t>(8, (grid + 7) / 8 * 8);              // persistent workgroups, the same number on every XCD
