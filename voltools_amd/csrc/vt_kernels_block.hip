@@ -29,6 +29,7 @@
 #include "vt_device.h"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace vt {
 
@@ -45,28 +46,45 @@ __device__ __forceinline__ void lds_read_b64(v2f& r, unsigned a)
 
 __device__ __forceinline__ v2f pk_fma(v2f a, float w, v2f c) { return __builtin_elementwise_fma(a, (v2f)(w), c); }
 
+// bspline_weights (bspline.h:102-112) for one fraction, evaluated on the pair (f, 1 - f): the formulas for (w3, w0) and for (w1, w2) are
+// the same expression in f and in 1 - f, so each pair is one packed instruction sequence -- operation for operation what
+// vt_device.h::bspline_weights does per weight (same rounding), seven instructions per axis instead of thirteen.
+__device__ __forceinline__ void bspline_weights_pk(float f, v2f& w30, v2f& w12)
+{
+    const v2f fg = {f, 1.0f - f};
+    const v2f sq = fg * fg;
+    w30 = ((v2f)(1.0f / 6.0f) * sq) * fg;                                        // {w3, w0}
+    const v2f t = (v2f)(2.0f) - fg;
+    w12 = (v2f)(2.0f / 3.0f) - ((v2f)(0.5f) * sq) * t;                            // {w1, w2} (contracted to one packed FMA, as the scalar form is)
+}
+
 // 64 taps of one voxel.  a0 = LDS byte address of column e (even) of tap row (z tap 0, y tap 0); ps4 = plane stride in bytes.
 template <bool SIMPLE, int RS>
 __device__ __forceinline__ float cubic_block_sample(unsigned a0, unsigned ps4, int par, float fz, float fy, float fx)
 {
     constexpr int RS4 = RS * 4;
     float wx[4], wy[4], wz[4];
-    cubic_weights<SIMPLE>(fx, wx);
-    cubic_weights<SIMPLE>(fy, wy);
-    cubic_weights<SIMPLE>(fz, wz);
-    // taps e+par .. e+par+3 of the six values (e .. e+5): picked by the parity at the end; par = 0 re-reads the second pair as
-    // the third, so nothing beyond the row's taps is touched
-    const unsigned off3 = par ? 16u : 8u;
-    unsigned a[4], b[4];
+    if constexpr (SIMPLE) {
+        cubic_weights<true>(fx, wx);
+        cubic_weights<true>(fy, wy);
+        cubic_weights<true>(fz, wz);
+    } else {
+        v2f a30, a12;
+        bspline_weights_pk(fx, a30, a12); wx[0] = a30.y; wx[1] = a12.x; wx[2] = a12.y; wx[3] = a30.x;
+        bspline_weights_pk(fy, a30, a12); wy[0] = a30.y; wy[1] = a12.x; wy[2] = a12.y; wy[3] = a30.x;
+        bspline_weights_pk(fz, a30, a12); wz[0] = a30.y; wz[1] = a12.x; wz[2] = a12.y; wz[3] = a30.x;
+    }
+    // The six values e .. e+5 of a row are three aligned pairs at fixed offsets; the taps are e+par .. e+par+3, picked by the parity at
+    // the end.  (par = 0 does not need the third pair: it is read all the same -- one address register per plane, every read an
+    // immediate offset -- and never selected; the row stride always holds it, vt_plan.hip: lx_used.)
+    unsigned a[4];
     a[0] = a0; a[1] = a0 + ps4; a[2] = a[1] + ps4; a[3] = a[2] + ps4;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) b[c] = a[c] + off3;
 
     // eight batches of two tap rows (6 reads); two batches in flight
     v2f t[2][6];
 #define VT_BLK_ISSUE(c, h, r)                                                                                                   \
-    lds_read_b64<(2 * h) * RS4>(r[0], a[c]); lds_read_b64<(2 * h) * RS4 + 8>(r[1], a[c]); lds_read_b64<(2 * h) * RS4>(r[2], b[c]);     \
-    lds_read_b64<(2 * h + 1) * RS4>(r[3], a[c]); lds_read_b64<(2 * h + 1) * RS4 + 8>(r[4], a[c]); lds_read_b64<(2 * h + 1) * RS4>(r[5], b[c]);
+    lds_read_b64<(2 * h) * RS4>(r[0], a[c]); lds_read_b64<(2 * h) * RS4 + 8>(r[1], a[c]); lds_read_b64<(2 * h) * RS4 + 16>(r[2], a[c]);     \
+    lds_read_b64<(2 * h + 1) * RS4>(r[3], a[c]); lds_read_b64<(2 * h + 1) * RS4 + 8>(r[4], a[c]); lds_read_b64<(2 * h + 1) * RS4 + 16>(r[5], a[c]);
 #define VT_BLK_WAIT(n, r) \
     asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]));
 #define VT_BLK_SUM(c, h, r)                                                                       \
@@ -91,7 +109,7 @@ __device__ __forceinline__ float cubic_block_sample(unsigned a0, unsigned ps4, i
 #undef VT_BLK_WAIT
 #undef VT_BLK_SUM
     // the four columns of the stencil out of the six column sums, by selects: the extra columns of the aligned window never enter
-    // the result (a zero weight would turn a non-finite neighbour into NaN)
+    // the result (a zero weight would turn a non-finite neighbour, or whatever an earlier tile left in an unstaged slot, into NaN)
     const float t0 = par ? S0.y : S0.x, t1 = par ? S1.x : S0.y, t2 = par ? S1.y : S1.x, t3 = par ? S2.x : S1.y;
     return fmaf(wx[3], t3, fmaf(wx[2], t2, fmaf(wx[1], t1, wx[0] * t0)));
 }
@@ -161,12 +179,12 @@ __device__ __forceinline__ void affine_block_body(const float* __restrict__ src,
         bool used = v < total && y < Ly && cx < nvx_used;
         if (used && (p.flags & (1 << 25))) {
             // Footprint trimming: of row (z, y) of the box only the columns some tile voxel can reach are staged -- the span that
-            // packed_row_span (vt_internal.h) proves for EVERY sub-voxel position of a tile, widened by the column on either side
-            // that the aligned 6-wide window of the cubic gather may read with weight 0.  The LDS image keeps the box's strides, so
-            // the gather is unchanged; unstaged slots keep whatever an earlier tile left there and are never read.
+            // packed_row_span (vt_internal.h) proves for EVERY sub-voxel position of a tile.  The LDS image keeps the box's strides, so
+            // the gather is unchanged; unstaged slots keep whatever an earlier tile left there: the aligned 6-wide window of the cubic
+            // gather may read such a slot, and drops it by a select.
             int mn, mx;
             used = packed_row_span(geo, z, y, &mn, &mx);
-            used = used && cx >= ((max(mn - HALO, 0)) >> 2) && cx <= ((mx + HALO) >> 2);
+            used = used && cx >= (mn >> 2) && cx <= (mx >> 2);
         }
         voff[k] = used ? z * plane_b + y * row_b + 16 * cx : 0;
     }
@@ -187,26 +205,34 @@ __device__ __forceinline__ void affine_block_body(const float* __restrict__ src,
         for (int r = 0; r < 3; ++r) {
             inc_hi[k][r] = p.binc_hi[k][r];
             inc_lo[k][r] = p.binc_lo[k][r];
-            if constexpr (PIN) asm volatile("" : "+v"(inc_hi[k][r]), "+v"(inc_lo[k][r]));
+            // (the half-height kernel walks w+8, d+4, w-8: kinds 0, 3, 2 -- 18 registers it can afford)
+            if (PIN || k == 0 || k == 2 || k == 3) asm volatile("" : "+v"(inc_hi[k][r]), "+v"(inc_lo[k][r]));
         }
-    // ... and so do the float64 constants of the tile geometry (float64 arithmetic is vector arithmetic anyway)
+    // ... and so do the float64 constants of the tile geometry (float64 arithmetic is vector arithmetic anyway) where registers are
+    // plentiful (PIN).  The half-height kernel (128 registers) reads them afresh for every tile instead, through a kernel-argument
+    // pointer the compiler cannot see through: hoisted out of the tile loop these ~70 scalar registers stayed live across the voxel loop,
+    // and the allocator's spills (v_readlane per use) landed on values the voxel loop reads -- 10 readlanes per voxel, ~100 per tile.
     double gm[12], gneg[3], gpos[3], gvlo[3], gvhi[3];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) { gm[i] = p.m[i]; if constexpr (PIN) asm volatile("" : "+v"(gm[i])); }
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        gneg[r] = p.neg[r]; gpos[r] = p.pos[r]; gvlo[r] = p.vlo[r]; gvhi[r] = p.vhi[r];
-        if constexpr (PIN) asm volatile("" : "+v"(gneg[r]), "+v"(gpos[r]), "+v"(gvlo[r]), "+v"(gvhi[r]));
-    }
-    // canonical_inside (vt_device.h) on the register copies of the matrix: the same float64 chain in the original problem's column order
+    double mp[3][3];                                              // matrix columns in the order of canonical_inside's chain (vt_device.h)
     const int oc0 = p.ord[0], oc1 = p.ord[1], oc2 = p.ord[2];
-    double mp[3][3];                                              // matrix columns in the chain's order
+    auto load_consts = [&](auto kp) {
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        mp[r][0] = oc0 == 0 ? p.m[4 * r] : (oc0 == 1 ? p.m[4 * r + 1] : p.m[4 * r + 2]);
-        mp[r][1] = oc1 == 0 ? p.m[4 * r] : (oc1 == 1 ? p.m[4 * r + 1] : p.m[4 * r + 2]);
-        mp[r][2] = oc2 == 0 ? p.m[4 * r] : (oc2 == 1 ? p.m[4 * r + 1] : p.m[4 * r + 2]);
-        if constexpr (PIN) asm volatile("" : "+v"(mp[r][0]), "+v"(mp[r][1]), "+v"(mp[r][2]));
+        for (int i = 0; i < 12; ++i) gm[i] = kp->m[i];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            gneg[r] = kp->neg[r]; gpos[r] = kp->pos[r]; gvlo[r] = kp->vlo[r]; gvhi[r] = kp->vhi[r];
+            mp[r][0] = oc0 == 0 ? kp->m[4 * r] : (oc0 == 1 ? kp->m[4 * r + 1] : kp->m[4 * r + 2]);
+            mp[r][1] = oc1 == 0 ? kp->m[4 * r] : (oc1 == 1 ? kp->m[4 * r + 1] : kp->m[4 * r + 2]);
+            mp[r][2] = oc2 == 0 ? kp->m[4 * r] : (oc2 == 1 ? kp->m[4 * r + 1] : kp->m[4 * r + 2]);
+        }
+    };
+    if constexpr (PIN) {
+        load_consts(&p);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) asm volatile("" : "+v"(gm[i]));
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            asm volatile("" : "+v"(gneg[r]), "+v"(gpos[r]), "+v"(gvlo[r]), "+v"(gvhi[r]), "+v"(mp[r][0]), "+v"(mp[r][1]), "+v"(mp[r][2]));
     }
     double toff[3];                                               // M.(vd, vh, vw): this thread's first voxel relative to the tile's
 #pragma unroll
@@ -268,6 +294,13 @@ __device__ __forceinline__ void affine_block_body(const float* __restrict__ src,
         td_i = (int)(sbd * 4 + (l6 >> 4)); th_i = (int)(sbh * 4 + ((l6 >> 2) & 3)); tw_i = (int)(sbw * 4 + (l6 & 3));
         const bool tile_ok = td_i < p.nTd && th_i < p.nTh && tw_i < p.nTw;
         if (!tile_ok) continue;
+        if constexpr (!PIN) {
+            // AffineParams follows the four pointer arguments of both kernels below (byte 32 of the kernel-argument segment)
+            typedef const __attribute__((address_space(4))) char* KArg;
+            KArg ka = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(ka));
+            load_consts((const __attribute__((address_space(4))) AffineParams*)(ka + 32));
+        }
         const int d0 = td_i * TD, h0 = th_i * TH, w0 = tw_i * TW;
 
         // ---- tile geometry (wave-uniform, float64) ----
@@ -326,7 +359,21 @@ __device__ __forceinline__ void affine_block_body(const float* __restrict__ src,
         __syncthreads();
 
         // ---- gather ----
-        const bool fast = all_valid && whole;
+        // Which of this thread's voxels store their value / a zero: all of them on tiles wholly inside the output and the valid interval
+        // (all but the rim of the volume); on the others the canonical float64 test runs here, ahead of the gather, so that the voxel
+        // loop below carries two bit tests per voxel instead of the tests' operands (15 of 210 instructions, formed for every voxel).
+        unsigned inmask = (1u << NS) - 1u, zmask = 0u;
+        if (!(all_valid && whole)) {
+            inmask = 0u;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int d = d0 + vd + sd[s], h = h0 + vh + sh[s], w = w0 + vw + sw[s];
+                if (d < p.oD && h < p.oH && w < p.oW) {
+                    if (inside_canonical(d, h, w)) inmask |= 1u << s;
+                    else if (!keep) zmask |= 1u << s;
+                }
+            }
+        }
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             float val;
@@ -350,25 +397,23 @@ __device__ __forceinline__ void affine_block_body(const float* __restrict__ src,
                 const float y1 = fmaf(fy, x11 - x10, x10);
                 val = fmaf(fz, y1 - y0, y0);
             }
+            asm volatile("" : "+v"(val));                          // (this voxel's sums are complete before the next voxel's reads: see below)
             const int soff = (sd[s] >> 2) * ostep_d + (sh[s] >> 3) * ostep_h + 4 * sw[s];
             if (no_stores) {
                 if (val == 123.456f) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), orsrc, obase, soff, 0);
-            } else if (fast) {
+            } else if ((inmask >> s) & 1u) {
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), orsrc, obase, soff, 0);
-            } else {
-                // tiles cut by the skirt or by the end of the output: the inside test is the canonical float64 chain
-                const int d = d0 + vd + sd[s], h = h0 + vh + sh[s], w = w0 + vw + sw[s];
-                if (d < p.oD && h < p.oH && w < p.oW) {
-                    const bool inside = inside_canonical(d, h, w);
-                    if (inside) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), orsrc, obase, soff, 0);
-                    else if (!keep) __builtin_amdgcn_raw_buffer_store_b32(0u, orsrc, obase, soff, 0);
-                }
+            } else if ((zmask >> s) & 1u) {
+                __builtin_amdgcn_raw_buffer_store_b32(0u, orsrc, obase, soff, 0);
             }
             if (s < NS - 1) {
 #pragma unroll
                 for (int r = 0; r < 3; ++r) fx_step(c[r], inc_hi[which[s]][r], inc_lo[which[s]][r]);
             }
-            // (no scheduling barrier: at 2 waves per SIMD the compiler may overlap the next voxel's weights with this one's taps)
+            // One voxel at a time: this voxel's value and the next voxel's coordinates pass through volatile asm statements, which keep
+            // their order among this voxel's reads and waits and the next one's.  Without them the loop body is one basic block, the
+            // compiler lets one voxel's sums sink below the next voxel's 48 reads, needs 256 registers and spills 79.
+            asm volatile("" : "+v"(c[0].hi), "+v"(c[0].lo), "+v"(c[1].hi), "+v"(c[1].lo), "+v"(c[2].hi), "+v"(c[2].lo));
         }
     }
     if (tid == 0) {
