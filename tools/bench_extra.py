@@ -35,10 +35,15 @@ def resident(n, interp, nsteps):
     out = vt.empty((n, n, n), device='gpu:0')
     c = np.divide(np.subtract((n, n, n), 1), 2, dtype=np.float32)
     mats = [vt.utils.transform_matrix(rotation=(0, float(i), 0), center=c) for i in range(nsteps)]
+    # The FIRST sweep of a fresh handle also builds the lazily created resident copies (plane-quad, and the in-plane transposed copy
+    # from 45 degrees on): that is the honest figure for the README loop run once (`/root/reference/README.md:25-27`); the second sweep is
+    # the steady state bench.py's headline line measures.  Both are printed.
+    cold_ms = sweep(sv, out, mats)
     total_ms = sweep(sv, out, mats)
     info = sv.info()
     res = {'size': n, 'interpolation': interp, 'steps': nsteps, 'total_ms': round(total_ms, 3),
-           'ms_per_step': round(total_ms / nsteps, 4), 'Mvoxels_per_s': round(n ** 3 * nsteps / total_ms / 1e3, 1),
+           'ms_per_step': round(total_ms / nsteps, 4), 'cold_first_sweep_total_ms': round(cold_ms, 3),
+           'cold_first_sweep_ms_per_step': round(cold_ms / nsteps, 4), 'Mvoxels_per_s': round(n ** 3 * nsteps / total_ms / 1e3, 1),
            'algorithmic_GBps': round(8.0 * n ** 3 * nsteps / total_ms / 1e6, 1), 'prefilter_ms_once': round(float(info.prefilter_ms), 3),
            'create_wall_s_incl_upload': round(create_s, 3), 'kernel': int(info.last_kernel), 'resident_GiB': round(info.resident_bytes / 2 ** 30, 2)}
     sv.close()

@@ -36,7 +36,7 @@ namespace vt {
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 constexpr int kBlkTD = 8, kBlkTW = 16;         // tile depth and width; the height is a template parameter: 16 (two workgroups per CU) or 8 (four)
-constexpr int block_max_it(int th) { return th == 16 ? 20 : 10; }      // staging vectors per thread: boxes up to 80 KiB / 40 KiB
+constexpr int block_max_it(int th) { return th == 16 ? 20 : 13; }      // staging vectors per thread: boxes up to 80 KiB / 52 KiB (four workgroups per CU up to 40 KiB, three beyond)
 
 template <int OFF>
 __device__ __forceinline__ void lds_read_b64(v2f& r, unsigned a)
@@ -219,15 +219,25 @@ __device__ __forceinline__ void affine_block_body(const float* __restrict__ src,
 #pragma unroll
         for (int i = 0; i < 12; ++i) gm[i] = kp->m[i];
 #pragma unroll
+        for (int r = 0; r < 3; ++r) { gneg[r] = kp->neg[r]; gpos[r] = kp->pos[r]; gvlo[r] = kp->vlo[r]; gvhi[r] = kp->vhi[r]; }
+    };
+    // (the chain's columns: as selects on registers where the matrix is pinned, as indexed loads where it is re-read per tile -- there a
+    // select chain became fifteen scalar instructions per entry, per tile)
+    auto load_chain = [&](auto kp) {
+#pragma unroll
         for (int r = 0; r < 3; ++r) {
-            gneg[r] = kp->neg[r]; gpos[r] = kp->pos[r]; gvlo[r] = kp->vlo[r]; gvhi[r] = kp->vhi[r];
-            mp[r][0] = oc0 == 0 ? kp->m[4 * r] : (oc0 == 1 ? kp->m[4 * r + 1] : kp->m[4 * r + 2]);
-            mp[r][1] = oc1 == 0 ? kp->m[4 * r] : (oc1 == 1 ? kp->m[4 * r + 1] : kp->m[4 * r + 2]);
-            mp[r][2] = oc2 == 0 ? kp->m[4 * r] : (oc2 == 1 ? kp->m[4 * r + 1] : kp->m[4 * r + 2]);
+            if constexpr (PIN) {
+                mp[r][0] = oc0 == 0 ? kp->m[4 * r] : (oc0 == 1 ? kp->m[4 * r + 1] : kp->m[4 * r + 2]);
+                mp[r][1] = oc1 == 0 ? kp->m[4 * r] : (oc1 == 1 ? kp->m[4 * r + 1] : kp->m[4 * r + 2]);
+                mp[r][2] = oc2 == 0 ? kp->m[4 * r] : (oc2 == 1 ? kp->m[4 * r + 1] : kp->m[4 * r + 2]);
+            } else {
+                mp[r][0] = kp->m[4 * r + oc0]; mp[r][1] = kp->m[4 * r + oc1]; mp[r][2] = kp->m[4 * r + oc2];
+            }
         }
     };
     if constexpr (PIN) {
         load_consts(&p);
+        load_chain(&p);
 #pragma unroll
         for (int i = 0; i < 12; ++i) asm volatile("" : "+v"(gm[i]));
 #pragma unroll
@@ -365,6 +375,12 @@ __device__ __forceinline__ void affine_block_body(const float* __restrict__ src,
         unsigned inmask = (1u << NS) - 1u, zmask = 0u;
         if (!(all_valid && whole)) {
             inmask = 0u;
+            if constexpr (!PIN) {
+                typedef const __attribute__((address_space(4))) char* KArg;
+                KArg ka = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
+                asm volatile("" : "+s"(ka));
+                load_chain((const __attribute__((address_space(4))) AffineParams*)(ka + 32));
+            }
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int d = d0 + vd + sd[s], h = h0 + vh + sh[s], w = w0 + vw + sw[s];
