@@ -89,6 +89,11 @@ __global__ __launch_bounds__(256, (KIND == 0 ? 3 : 2)) void affine_tiled_packed(
 
     const int ntiles = p.nTd * p.nTh * p.nTw;
     const bool keep = (p.flags & VT_KEEP_OUTSIDE) != 0;
+    // this thread's columns relative to the tile's first voxel, M[:, 1:3].(j, kw): formed once per launch (the tile loop adds the tile's base)
+    // (one column per thread only: two columns' offsets cost the 8 x 16 x 32 tile's kernel eleven spilled registers)
+    double coff[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) coff[r] = fma(p.m[4 * r + 1], (double)(tid / TW), p.m[4 * r + 2] * (double)(tid % TW));
     const int64_t ostride = (int64_t)p.oH * p.oW;
     const int kw = tid % TW;
     const int jh0 = tid / TW;
@@ -253,17 +258,29 @@ __global__ __launch_bounds__(256, (KIND == 0 ? 3 : 2)) void affine_tiled_packed(
                 const int wave_first = __builtin_amdgcn_readfirstlane(tid & ~63);
                 const unsigned buf_addr = __builtin_amdgcn_readfirstlane(
                     (unsigned)(size_t)(__attribute__((address_space(3))) void*)buf);
+                if (box_inside) {
+                    // the whole box is inside the volume (all but the rim): one descriptor based at the box origin, the vector's byte
+                    // offset as the instruction's vector offset -- no 64-bit address arithmetic and no bounds test per vector
+                    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<char*>(reinterpret_cast<const char*>(src + origin)), 0, 0x7fffffff, 0x00020000);
+                    char* dst = reinterpret_cast<char*>(buf) + 16 * wave_first;
 #pragma unroll
-                for (int it = 0; it < kPackMaxIt; ++it) {
-                    const int v0 = wave_first + 256 * it;
-                    if (v0 < nvec) {                              // wave-uniform
-                        const float* g = src + origin + rel[it];
-                        if (!box_inside) {
+                    for (int it = 0; it < kPackMaxIt; ++it) {
+                        if (wave_first + 256 * it < nvec) {           // wave-uniform
+                            if (tid + 256 * it < nvec && !no_loads)
+                                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + 4096 * it), 16, 4 * rel[it], 0, 0, 0);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int it = 0; it < kPackMaxIt; ++it) {
+                        const int v0 = wave_first + 256 * it;
+                        if (v0 < nvec) {                              // wave-uniform
                             const int gz = o[0] + (zyx[it] >> 22), gy = o[1] + ((zyx[it] >> 12) & 0x3ff), gx = o[2] + (zyx[it] & 0xfff);
                             const bool inb = (unsigned)gz < (unsigned)p.sD && (unsigned)gy < (unsigned)p.sH && (unsigned)gx < (unsigned)p.sP;
-                            g = inb ? g : zeros16;
+                            const float* g = inb ? src + origin + rel[it] : zeros16;
+                            if (tid + 256 * it < nvec && !no_loads) lds_dma16(g, buf_addr + 16u * (unsigned)v0);
                         }
-                        if (tid + 256 * it < nvec && !no_loads) lds_dma16(g, buf_addr + 16u * (unsigned)v0);
                     }
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the direct-to-LDS loads are invisible to hipcc's counters
@@ -286,9 +303,9 @@ __global__ __launch_bounds__(256, (KIND == 0 ? 3 : 2)) void affine_tiled_packed(
 #pragma unroll
                         for (int jj = 0; jj < NJ; ++jj) {
                             const int j = jh0 + jj * RP;
-                            const Fx f0 = to_fx(fma(p.m[1], (double)j, fma(p.m[2], (double)kw, b[0])));
-                            const Fx f1 = to_fx(fma(p.m[5], (double)j, fma(p.m[6], (double)kw, b[1])));
-                            const Fx f2 = to_fx(fma(p.m[9], (double)j, fma(p.m[10], (double)kw, b[2])));
+                            const Fx f0 = NJ == 1 ? to_fx(b[0] + coff[0]) : to_fx(fma(p.m[1], (double)j, fma(p.m[2], (double)kw, b[0])));
+                            const Fx f1 = NJ == 1 ? to_fx(b[1] + coff[1]) : to_fx(fma(p.m[5], (double)j, fma(p.m[6], (double)kw, b[1])));
+                            const Fx f2 = NJ == 1 ? to_fx(b[2] + coff[2]) : to_fx(fma(p.m[9], (double)j, fma(p.m[10], (double)kw, b[2])));
                             uint64_t c0 = ((uint64_t)(uint32_t)f0.hi << 32) | f0.lo;
                             uint64_t c1 = ((uint64_t)(uint32_t)f1.hi << 32) | f1.lo;
                             uint64_t c2 = ((uint64_t)(uint32_t)f2.hi << 32) | f2.lo;
