@@ -114,10 +114,14 @@ __device__ __forceinline__ float cubic_block_sample(unsigned a0, unsigned ps4, i
     return fmaf(wx[3], t3, fmaf(wx[2], t2, fmaf(wx[1], t1, wx[0] * t0)));
 }
 
-// Stage the box with per-vector bounds tests (tiles whose box leaves the volume): vectors outside come from a block of zeros.
+// Stage the box with per-vector bounds tests (tiles whose box leaves the volume: the rim, a third of the tiles of a rotated cube together
+// with the tiles outside): vectors outside come from a block of zeros.  Round 4: the thread's own trimmed descriptors voff[] (0 = not
+// staged) instead of the whole box, the vector's (z, y, x) by the set-up's multiply-high and a compile-time division instead of two
+// run-time integer divisions: ~25 instead of ~90 instructions per vector, a third of the vectors.
+// (the full-height kernel, 20 descriptors and 226 registers, keeps round 2's rolled loop over the whole box: the unrolled form spills there)
 template <int RS>
-__device__ __forceinline__ void stage_block_checked(float* lds, const float* __restrict__ src, const float* __restrict__ zeros16,
-                                                    const AffineParams& p, const int (&o)[3], int total, int psv, int nvx_used, int tid)
+__device__ __forceinline__ void stage_block_checked_box(float* lds, const float* __restrict__ src, const float* __restrict__ zeros16,
+                                                        const AffineParams& p, const int (&o)[3], int total, int psv, int nvx_used, int tid)
 {
     constexpr int nvx = RS / 4;
     const int wave_first = __builtin_amdgcn_readfirstlane(tid & ~63);
@@ -131,6 +135,30 @@ __device__ __forceinline__ void stage_block_checked(float* lds, const float* __r
         const float* g = inb ? src + (((int64_t)gz * p.sH + gy) * p.sP + gx) : zeros16;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                          (__attribute__((address_space(3))) void*)(lds + 4 * vb), 16, 0, 0);
+    }
+}
+
+template <int RS, int MAXIT>
+__device__ __forceinline__ void stage_block_checked(float* lds, const float* __restrict__ src, const float* __restrict__ zeros16,
+                                                    const AffineParams& p, const int (&o)[3], const int (&voff)[MAXIT], int total, int psv, int tid)
+{
+    constexpr int nvx = RS / 4;
+    const int wave_first = __builtin_amdgcn_readfirstlane(tid & ~63);
+    const char* const origin = reinterpret_cast<const char*>(src + (((int64_t)o[0] * p.sH + o[1]) * p.sP + o[2]));
+#pragma unroll
+    for (int k = 0; k < MAXIT; ++k) {
+        if (k * 256 + wave_first < total) {                      // wave-uniform
+            int v = k * 256 + tid;
+            asm volatile("" : "+v"(v));                          // (one vector at a time: the unrolled loop's address arithmetic, hoisted, spills)
+            const int z = (int)__umulhi((unsigned)v, p.psv_magic), rem = v - z * psv;      // as in the set-up: v / psv
+            const int y = rem / nvx, cx = rem - y * nvx;
+            const int gz = o[0] + z, gy = o[1] + y, gx = o[2] + 4 * cx;
+            const bool inb = (unsigned)gz < (unsigned)p.sD && (unsigned)gy < (unsigned)p.sH && (unsigned)gx < (unsigned)p.sP;
+            const float* g = inb ? reinterpret_cast<const float*>(origin + voff[k]) : zeros16;
+            if (voff[k] != 0 || v == 0)                          // (vector 0 is always staged: its offset is 0 too)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                 (__attribute__((address_space(3))) void*)(lds + 4 * (k * 256 + wave_first)), 16, 0, 0);
+        }
     }
 }
 
@@ -215,34 +243,32 @@ __device__ __forceinline__ void affine_block_body(const float* __restrict__ src,
     double gm[12], gneg[3], gpos[3], gvlo[3], gvhi[3];
     double mp[3][3];                                              // matrix columns in the order of canonical_inside's chain (vt_device.h)
     const int oc0 = p.ord[0], oc1 = p.ord[1], oc2 = p.ord[2];
-    auto load_consts = [&](auto kp) {
+    auto load_consts = [&](const auto& kp_) {
+        const auto* const kp = &kp_;
 #pragma unroll
         for (int i = 0; i < 12; ++i) gm[i] = kp->m[i];
 #pragma unroll
         for (int r = 0; r < 3; ++r) { gneg[r] = kp->neg[r]; gpos[r] = kp->pos[r]; gvlo[r] = kp->vlo[r]; gvhi[r] = kp->vhi[r]; }
     };
-    // (the chain's columns: as selects on registers where the matrix is pinned, as indexed loads where it is re-read per tile -- there a
-    // select chain became fifteen scalar instructions per entry, per tile)
-    auto load_chain = [&](auto kp) {
+    // (the chain's columns: selects among the PINNED register copies of the matrix where it is pinned -- a select between two loads from
+    // the argument struct becomes a select of two addresses, and the struct then lives on the stack: 528 bytes of scratch per thread --,
+    // indexed loads where it is re-read per tile: there a select chain became fifteen scalar instructions per entry, per tile)
+    auto load_chain = [&](const auto& kp_) {
+        const auto* const kp = &kp_;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            if constexpr (PIN) {
-                mp[r][0] = oc0 == 0 ? kp->m[4 * r] : (oc0 == 1 ? kp->m[4 * r + 1] : kp->m[4 * r + 2]);
-                mp[r][1] = oc1 == 0 ? kp->m[4 * r] : (oc1 == 1 ? kp->m[4 * r + 1] : kp->m[4 * r + 2]);
-                mp[r][2] = oc2 == 0 ? kp->m[4 * r] : (oc2 == 1 ? kp->m[4 * r + 1] : kp->m[4 * r + 2]);
-            } else {
-                mp[r][0] = kp->m[4 * r + oc0]; mp[r][1] = kp->m[4 * r + oc1]; mp[r][2] = kp->m[4 * r + oc2];
-            }
-        }
+        for (int r = 0; r < 3; ++r) { mp[r][0] = kp->m[4 * r + oc0]; mp[r][1] = kp->m[4 * r + oc1]; mp[r][2] = kp->m[4 * r + oc2]; }
     };
     if constexpr (PIN) {
-        load_consts(&p);
-        load_chain(&p);
+        load_consts(p);
 #pragma unroll
         for (int i = 0; i < 12; ++i) asm volatile("" : "+v"(gm[i]));
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+        for (int r = 0; r < 3; ++r) {
+            mp[r][0] = oc0 == 0 ? gm[4 * r] : (oc0 == 1 ? gm[4 * r + 1] : gm[4 * r + 2]);
+            mp[r][1] = oc1 == 0 ? gm[4 * r] : (oc1 == 1 ? gm[4 * r + 1] : gm[4 * r + 2]);
+            mp[r][2] = oc2 == 0 ? gm[4 * r] : (oc2 == 1 ? gm[4 * r + 1] : gm[4 * r + 2]);
             asm volatile("" : "+v"(gneg[r]), "+v"(gpos[r]), "+v"(gvlo[r]), "+v"(gvhi[r]), "+v"(mp[r][0]), "+v"(mp[r][1]), "+v"(mp[r][2]));
+        }
     }
     double toff[3];                                               // M.(vd, vh, vw): this thread's first voxel relative to the tile's
 #pragma unroll
@@ -309,7 +335,7 @@ __device__ __forceinline__ void affine_block_body(const float* __restrict__ src,
             typedef const __attribute__((address_space(4))) char* KArg;
             KArg ka = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(ka));
-            load_consts((const __attribute__((address_space(4))) AffineParams*)(ka + 32));
+            load_consts(*(const __attribute__((address_space(4))) AffineParams*)(ka + 32));
         }
         const int d0 = td_i * TD, h0 = th_i * TH, w0 = tw_i * TW;
 
@@ -358,7 +384,8 @@ __device__ __forceinline__ void affine_block_body(const float* __restrict__ src,
                 if (k * 256 + wave_first < total)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + 4096 * k), 16, voff[k], 0, 0, 0);
         } else {
-            stage_block_checked<RS>(lds, src, zeros16, p, o, total, psv, nvx_used, tid);
+            if constexpr (TH == 16) stage_block_checked_box<RS>(lds, src, zeros16, p, o, total, psv, nvx_used, tid);
+            else stage_block_checked<RS, kBlkMaxIt>(lds, src, zeros16, p, o, voff, total, psv, tid);
         }
         // this thread's first voxel, box coordinates in Q32.32 (while the loads are in flight): the tile's base plus the thread's own
         // offset M.(vd, vh, vw), which is formed once per launch
@@ -379,7 +406,7 @@ __device__ __forceinline__ void affine_block_body(const float* __restrict__ src,
                 typedef const __attribute__((address_space(4))) char* KArg;
                 KArg ka = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
                 asm volatile("" : "+s"(ka));
-                load_chain((const __attribute__((address_space(4))) AffineParams*)(ka + 32));
+                load_chain(*(const __attribute__((address_space(4))) AffineParams*)(ka + 32));
             }
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
@@ -477,17 +504,18 @@ void block_tile(int th, int* td, int* tw) { (void)th; *td = kBlkTD; *tw = kBlkTW
 template <int RS, int TH>
 static block_fn pick_block_kind(int kind)
 {
-    if (TH == 16) {
+    if constexpr (TH == 16) {
         switch (kind) {
             case 0: return affine_block<0, RS>;
             case 1: return affine_block<1, RS>;
             default: return affine_block<2, RS>;
         }
-    }
-    switch (kind) {
-        case 0: return affine_block_half<0, RS>;
-        case 1: return affine_block_half<1, RS>;
-        default: return affine_block_half<2, RS>;
+    } else {
+        switch (kind) {
+            case 0: return affine_block_half<0, RS>;
+            case 1: return affine_block_half<1, RS>;
+            default: return affine_block_half<2, RS>;
+        }
     }
 }
 
