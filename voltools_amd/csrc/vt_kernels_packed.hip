@@ -186,36 +186,48 @@ __global__ __launch_bounds__(256, (KIND == 0 ? 3 : 2)) void affine_tiled_packed(
     // the workgroups progress (tiles outside the volume cost nothing, tiles on its rim more than the others).  With static striding
     // the patch frays: [measured, 512^3, 100 random rotations] L2 hit rate of the launch 0.35, 2.19 GB of HBM-side traffic.
     // The next id is fetched while the current tile is gathered; the last workgroup to leave zeroes the counters.
-    int* const ctrl = scratch + 4;                               // (the wave sums of the set-up are dead)
+    // Round 4: the id of the next tile travels through one of two LDS words that thread 0 fills while the current tile is gathered; the
+    // barrier that ends a tile (the buffer is restaged next) also publishes it -- two barriers per tile instead of four --, and the tile
+    // decode divides by multiply-high with host constants (the packed kernel fetches ONE id at a time: both were per-tile costs).
+    int* const ctrl = scratch + 4;                               // ctrl[0], ctrl[1] (the wave sums of the set-up are dead)
     const bool plain_order = (p.flags & (1 << 23)) != 0;         // plain (d, h, w) order (VT_TILE_ORDER=0, experiments)
     const int nids = plain_order ? ntiles : blocked_tile_count(p.nTd, p.nTh, p.nTw);
+    const int nSh = (p.nTh + 3) >> 2, nSw = (p.nTw + 3) >> 2;
     const int xcd = blockIdx.x & 7, per = (((nids + 63) >> 6) + 7) / 8 * 64;      // ceil: plain order's tile count is no multiple of 64
     const int id0 = xcd * per, id_cnt = max(0, min(per, nids - id0));
     int* const counter = queue + 32 * xcd;
-    const int chunk = p.dch;
     int nxt = 0;
-    if (tid == 0) nxt = atomicAdd(counter, chunk);
-    int cur = 0, left = 0;
+    if (tid == 0) { ctrl[0] = atomicAdd(counter, 1); nxt = atomicAdd(counter, 1); }
+    __syncthreads();
+    int par = 0;
     for (;;) {
-        if (left == 0) {
-            if (tid == 0) ctrl[0] = nxt;
-            __syncthreads();                                     // the next chunk is visible
-            cur = ctrl[0];
-            left = chunk;
-            __syncthreads();                                     // everyone has read it before thread 0 may overwrite it
-            if (cur >= id_cnt) break;
-            if (tid == 0) nxt = atomicAdd(counter, chunk);
-        }
+        const int cur = ctrl[par];                                // published by the barrier that ended the previous tile
+        if (cur >= id_cnt) break;
+        par ^= 1;
+        // every path through a tile ends in publish_and_sync(): thread 0 stores the next id, one barrier makes it visible (and, where the
+        // tile was staged, ends the reads of the buffer)
+        auto publish_and_sync = [&]() {
+            if (tid == 0) { ctrl[par] = nxt; nxt = atomicAdd(counter, 1); }
+            __syncthreads();
+        };
         const int t = id0 + cur;
-        ++cur; --left;
-        if (cur > id_cnt) continue;
         int td_i, th_i, tw_i;
+        bool tile_ok = true;
         if (plain_order) {
             tw_i = t % p.nTw;
             const int t2 = t / p.nTw;
             th_i = t2 % p.nTh;
             td_i = t2 / p.nTh;
-        } else if (!blocked_tile(t, p.nTd, p.nTh, p.nTw, td_i, th_i, tw_i)) continue;
+        } else {
+            // blocked_tile (vt_device.h) with its two divisions as multiply-high by host constants (vt_plan.hip: the magic numbers of the
+            // super-block counts along w and h; a count of 1 has no 32-bit magic number)
+            const unsigned sbi = (unsigned)t >> 6, l6 = (unsigned)t & 63u;
+            const unsigned s2 = nSw == 1 ? sbi : __umulhi(sbi, p.nTw_magic), sbw = sbi - s2 * (unsigned)nSw;
+            const unsigned sbd = nSh == 1 ? s2 : __umulhi(s2, p.nTh_magic), sbh = s2 - sbd * (unsigned)nSh;
+            td_i = (int)(sbd * 4 + (l6 >> 4)); th_i = (int)(sbh * 4 + ((l6 >> 2) & 3)); tw_i = (int)(sbw * 4 + (l6 & 3));
+            tile_ok = td_i < p.nTd && th_i < p.nTh && tw_i < p.nTw;
+        }
+        if (!tile_ok) { publish_and_sync(); continue; }
         const int d0 = td_i * TD, h0 = th_i * TH, w0 = tw_i * TW;
         const int nd = min(TD, p.oD - d0);
 
@@ -398,7 +410,7 @@ __global__ __launch_bounds__(256, (KIND == 0 ? 3 : 2)) void affine_tiled_packed(
                         fx_step(c2, p.inc_hi[2], p.inc_lo[2]);
                     }
                 }
-                __syncthreads();                                  // the buffer is restaged by the next tile
+                // (the barrier of publish_and_sync below ends the reads of the buffer: it is restaged by the next tile)
             } else {
                 // the packed footprint does not fit the buffer planned on the host: gather from global memory
 #pragma unroll
@@ -421,6 +433,7 @@ __global__ __launch_bounds__(256, (KIND == 0 ? 3 : 2)) void affine_tiled_packed(
                 }
             }
         }
+        publish_and_sync();
     }
     if (tid == 0) {
         __threadfence();

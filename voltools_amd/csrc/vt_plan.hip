@@ -818,6 +818,9 @@ bool plan_packed(PlanCtx& c, bool have_box, double box_bpv)
     // 4 ids per fetch: L2 hit 0.22, 2.47 GB of HBM-side traffic; 1: 0.56, 1.54 GB; static striding: 0.35, 2.19 GB).  Making the
     // output axis that follows source x the fastest one instead of w loses 3 % (the output lines are completed later).
     p->dch = 1;
+    // the kernel's tile decode divides super-block indices by the super-block counts along w and h: (u * magic) >> 32 == u / n
+    p->nTw_magic = (uint32_t)((1ULL << 32) / (uint64_t)((p->nTw + 3) >> 2) + 1);
+    p->nTh_magic = (uint32_t)((1ULL << 32) / (uint64_t)((p->nTh + 3) >> 2) + 1);
     return true;
 }
 
