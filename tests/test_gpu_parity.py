@@ -341,6 +341,39 @@ def test_prefilter_matches_oracle_all_axes_lengths():
         d.free()
 
 
+def test_prefilter_inplace_on_a_view_that_is_only_4_byte_aligned():
+    """`vt_prefilter_inplace` on a caller's device pointer that is an offset view (4-byte aligned) of a shape the fused X+Y pass would
+    otherwise take: the library must fall back to the separate passes, not fail."""
+    import ctypes
+    lib = _native.load()
+    for shape in [(6, 128, 512), (3, 161, 64), (5, 200, 72)]:
+        vol = rand_vol(shape, 23)
+        n = int(np.prod(shape))
+        buf = _native.DeviceArray((n + 8,), 0)
+        for off in (1, 2, 3):                          # floats: 4-, 8-, 12-byte offsets from a 256-byte-aligned allocation
+            host = np.zeros(n + 8, np.float32)
+            host[off:off + n] = vol.ravel()
+            buf.set(host)
+            _native.check(lib.vt_prefilter_inplace(0, ctypes.c_void_p(buf.ptr + 4 * off), *shape), 'vt_prefilter_inplace')
+            got = buf.get()
+            assert np.abs(got[off:off + n].reshape(shape) - oracle.prefilter(vol)).max() <= 5e-6, (shape, off)
+            assert not got[:off].any() and not got[off + n:].any()          # nothing outside the view was touched
+        buf.free()
+
+
+def test_packed_kernel_plain_tile_order_on_a_ragged_tile_count(monkeypatch):
+    """VT_TILE_ORDER=0 (plain (d, h, w) tile order, an experiment knob) with a tile count that is no multiple of 64: every tile must
+    still be computed (the per-XCD id partition rounded down and skipped the last tiles)."""
+    monkeypatch.setenv('VT_TILE_ORDER', '0')
+    for shape in ((72, 100, 130), (40, 136, 200)):
+        vol = rand_vol(shape, 31)
+        m = MATRICES['rot_general'](shape)
+        want = oracle.affine(vol, m, 'linear')
+        got, info = run_case(vol, m, 'linear', _native.FORCE_TILED | _native.NO_ZSEP | _native.FORCE_PACKED)
+        assert info.last_kernel == 6, info.last_kernel
+        assert np.abs(got - want).max() <= TOL['linear'], shape
+
+
 @pytest.mark.parametrize('shape', [(20, 47, 67), (9, 170, 101), (4, 290, 515), (3, 41, 64), (5, 161, 481)])
 def test_prefilter_fused_xy_on_pitched_rows(shape):
     """The fused X+Y pass on the resident (pitched) layout, widths that are not multiples of 4 or 8: the identity transform of a
