@@ -36,7 +36,7 @@ struct Tuning {
     int block_rs = -1;             // VT_BLOCK_RS: force the row-stride index of the lane-block kernel (if it holds the box)
     bool block_linear = false;     // VT_BLOCK_LINEAR: trilinear general matrices on the lane-block kernel too (slower than packed footprints)
     bool block_no_trim = false;    // VT_BLOCK_NO_TRIM: the lane-block kernel stages whole boxes (A/B of the footprint trimming)
-    int block_min = 256;           // VT_BLOCK_MIN: smallest output (cube edge) that general cubic launches take to the lane-block kernel
+    int block_min = 240;           // VT_BLOCK_MIN: smallest output (cube edge) that general cubic launches take to the lane-block kernel
     int block_pad = -1;            // VT_BLOCK_PAD: plane-stride padding in floats instead of the bank model's choice
     int block_th = 8;              // VT_BLOCK_TH: tile height of the lane-block kernel: 8 (8 x 8 x 16 tiles, four workgroups per CU; boxes beyond 40 KiB fall back to 16) or 16 (8 x 16 x 16, two per CU)
     void read()
@@ -77,7 +77,7 @@ struct Tuning {
         block_linear = std::getenv("VT_BLOCK_LINEAR") != nullptr;
         block_pad = num("VT_BLOCK_PAD", -1);
         block_th = num("VT_BLOCK_TH", 8) == 16 ? 16 : 8;
-        block_min = std::max(1, num("VT_BLOCK_MIN", 256));
+        block_min = std::max(1, num("VT_BLOCK_MIN", 240));
         block_no_trim = std::getenv("VT_BLOCK_NO_TRIM") != nullptr;
     }
 };

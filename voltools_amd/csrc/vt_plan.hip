@@ -876,7 +876,7 @@ bool plan_block_th(PlanCtx& c, int th)
     if (!c.cubic && !v->tune.block_linear) return false;
     // persistent workgroups want many tiles each: [measured, 100 random rotations, ms, lane blocks vs boxes] 160^3 0.071 / 0.050,
     // 200^3 0.112 / 0.090, 250^3 0.158 / 0.161, 288^3 0.212 / 0.223, 384^3 0.473 / 0.553, 512^3 1.05 / 1.23, 640^3 2.10 / 2.62
-    // (tools/general_ab.py, VT_BLOCK_MIN)
+    // (tools/general_ab.py, VT_BLOCK_MIN).  Round 4, half-height tiles: 200^3 0.109 / 0.090, 250^3 0.150 / 0.161, 288^3 0.194 -> the threshold is 240^3
     if (!(c.flags & VT_FORCE_TILED) && (int64_t)v->oD * v->oH * v->oW < (int64_t)v->tune.block_min * v->tune.block_min * v->tune.block_min) return false;
     // tile height 8 (8 x 8 x 16 voxels, boxes of at most 40 KiB, four workgroups per CU) or 16 (round 2's 8 x 16 x 16, two per CU)
     int T[3];
