@@ -6,8 +6,8 @@ max|volume|: the arithmetic is linear in the data), a constant volume (trilinear
 subnormal floats (gfx950 keeps float32 subnormals in v_fma / v_pk_fma: the kernels must not flush what the oracle keeps), and
 NaN / Inf placement: for every kernel family WHICH output voxels turn non-finite is pinned against the oracle's set -- every output whose
 stencil contains the bad voxel, also through a weight of exactly zero (0 * NaN = NaN, `helper_interpolation.h:3-6` has no special
-case) -- with the one documented exception of DESIGN section 2: the integer-axis-0-offset trilinear instantiation (`KIND 3`) never reads
-the tap plane whose weight is exactly 0.
+case) -- with the one documented exception of DESIGN section 2: the integer-axis-0-offset instantiations (`KIND 3` trilinear, `KIND 4` cubic)
+never read the tap plane whose weight is exactly 0.
 """
 import numpy as np
 import pytest
@@ -140,14 +140,15 @@ def test_nonfinite_placement(interp, badval):
             k = int(sv.info().last_kernel)
             got_bad = ~np.isfinite(got)
             allowed_missing = np.zeros(SHAPE, bool)
-            if interp == 'linear' and k == 8:
-                # KIND 3 (on the plain copy, or on an axis-exchanged one for rotations about axis 1 / 2): along the marching axis `a` (row a of
-                # the matrix is a unit row with an integer offset) output slice d reads source slice d + off only; the oracle also multiplies
-                # slice d + off + 1 by exactly 0
+            if k == 8:
+                # KIND 3 / KIND 4 (on the plain copy, or on an axis-exchanged one for rotations about axis 1 / 2): along the marching axis `a`
+                # (row a of the matrix is a unit row with an integer offset) trilinear output slice d reads source slice d + off only, the
+                # cubic one slices d + off - 1 .. d + off + 1 (through the z-convolved copy); the oracle also multiplies the next slice
+                # (d + off + 1, resp. d + off + 2) by exactly 0
                 for a in range(3):
                     unit = all(m64[a, c] == (1.0 if c == a else 0.0) for c in range(3))
                     if unit and m64[a, 3] == np.floor(m64[a, 3]):
-                        dz = bad[a] - int(m64[a, 3]) - 1
+                        dz = bad[a] - int(m64[a, 3]) - (1 if interp == 'linear' else 2)
                         if 0 <= dz < SHAPE[a]:
                             idx = [slice(None)] * 3
                             idx[a] = dz

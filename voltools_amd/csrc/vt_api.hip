@@ -361,6 +361,7 @@ struct Orientation {
     float** pair_slot = nullptr;       // where its plane-pair form lives (test build)
 #endif
     float** quad_slot = nullptr;       // where its plane-quad form lives
+    float** quade_slot = nullptr;      // ... and the plane-quad form of its z-convolved volume (cubic launches with an integer axis-0 offset)
     int quad_idx = 0;
     int srcD = 0, srcH = 0;            // depth / height of that copy
     int rowW = 0, rowP = 0;            // row width / pitch of that copy
@@ -428,7 +429,7 @@ int try_axis1_exchange(vt_volume* v, const double m[12], int flags, size_t n_out
     *p = ps; *plan = plans;
     p->ostride = v->oW; p->orow = (int64_t)v->oH * v->oW;
     p->ord[0] = 1; p->ord[1] = 0; p->ord[2] = 2;          // original (d, h, w) = this launch's columns (1, 0, 2)
-    ori->src_plain = v->d_src_t; ori->quad_slot = &v->d_src_t_q; ori->quad_idx = 1;
+    ori->src_plain = v->d_src_t; ori->quad_slot = &v->d_src_t_q; ori->quade_slot = &v->d_src_qe[1]; ori->quad_idx = 1;
 #ifdef VT_LEGACY
     ori->pair_slot = &v->d_src_t_zp;
 #endif
@@ -484,7 +485,7 @@ int try_axis2_exchange(vt_volume* v, const double m[12], int flags, size_t n_out
     }
     *p = ps; *plan = plans;
     p->ord[0] = 2; p->ord[1] = 1; p->ord[2] = 0;          // original (d, h, w) = this launch's columns (2, 1, 0)
-    ori->src_plain = v->d_src_x; ori->quad_slot = &v->d_src_x_q; ori->quad_idx = 3;
+    ori->src_plain = v->d_src_x; ori->quad_slot = &v->d_src_x_q; ori->quade_slot = &v->d_src_qe[3]; ori->quad_idx = 3;
 #ifdef VT_LEGACY
     ori->pair_slot = &v->d_src_x_zp;
 #endif
@@ -526,7 +527,7 @@ int try_inplane_transposed(vt_volume* v, const double m[12], int flags, size_t n
                                   v->Pr, (int64_t)v->W * v->Pr, v->stream));
     }
     *p = ps; *plan = plans;
-    ori->src_plain = v->d_src_r; ori->quad_slot = &v->d_src_r_q; ori->quad_idx = 2;
+    ori->src_plain = v->d_src_r; ori->quad_slot = &v->d_src_r_q; ori->quade_slot = &v->d_src_qe[2]; ori->quad_idx = 2;
 #ifdef VT_LEGACY
     ori->pair_slot = &v->d_src_r_zp;
 #endif
@@ -557,8 +558,9 @@ int ensure_secondary_copy(vt_volume* v, const TilePlan& plan, const AffineParams
 {
     float** slot = nullptr;
     size_t bytes = 0;
+    const bool zfir = plan.kind == 8 && (p.flags & (1 << 19)) != 0;       // the z-convolved copy (vt_plan.hip: plan_quad)
     if (plan.kind == 8) {
-        slot = ori.quad_slot;
+        slot = zfir ? ori.quade_slot : ori.quad_slot;
         bytes = (size_t)((ori.srcD + 3) / 4) * ori.srcH * p.sPq * sizeof(float);
 #ifdef VT_LEGACY
     } else if (plan.kind == 5) {
@@ -573,7 +575,7 @@ int ensure_secondary_copy(vt_volume* v, const TilePlan& plan, const AffineParams
     // A copy that did not fit is not attempted again at once: a device that is short of memory would pay a volume-sized hipMalloc
     // (and its failure) on every call.  The next attempt comes kCopyRetryCalls calls later.
     constexpr int kCopyRetryCalls = 64;
-    int* const retry = (plan.kind == 8) ? &v->copy_retry_in[ori.quad_idx] : nullptr;
+    int* const retry = (plan.kind == 8) ? &v->copy_retry_in[ori.quad_idx + (zfir ? 4 : 0)] : nullptr;
     if (retry && *retry > 0) { --*retry; return 1; }
     if (hipMalloc(reinterpret_cast<void**>(slot), bytes) != hipSuccess) {
         (void)hipGetLastError();              // no room for another copy of the volume: a family that reads the plain layout serves the call
@@ -583,7 +585,9 @@ int ensure_secondary_copy(vt_volume* v, const TilePlan& plan, const AffineParams
     }
     hipError_t e = hipMemsetAsync(*slot, 0, bytes, v->stream);       // positions beyond the row's width stay zero
     if (e == hipSuccess) {
-        if (plan.kind == 8)
+        if (zfir)
+            e = launch_relayout_zquad_fir(ori.src_plain, *slot, ori.srcD, ori.srcH, ori.rowW, ori.rowP, p.sPq, (p.flags & (1 << 18)) != 0, v->stream);
+        else if (plan.kind == 8)
             e = launch_relayout_zquad(ori.src_plain, *slot, ori.srcD, ori.srcH, ori.rowW, ori.rowP, p.sPq, v->stream);
 #ifdef VT_LEGACY
         else
@@ -600,7 +604,8 @@ int ensure_secondary_copy(vt_volume* v, const TilePlan& plan, const AffineParams
         return 1;
     }
     if (std::getenv("VT_DEBUG_ALLOC")) std::fprintf(stderr, "[vt] secondary copy kind %d orientation %d at %p, %zu bytes (plain source %p)\n", plan.kind, ori.quad_idx, (void*)*slot, bytes, (const void*)ori.src_plain);
-    if (plan.kind == 8) v->quad_bytes[ori.quad_idx] = bytes;
+    if (zfir) v->quade_bytes[ori.quad_idx] = bytes;
+    else if (plan.kind == 8) v->quad_bytes[ori.quad_idx] = bytes;
 #ifdef VT_LEGACY
     else v->P2 = p.sP2;
 #endif
@@ -611,14 +616,15 @@ int ensure_secondary_copy(vt_volume* v, const TilePlan& plan, const AffineParams
 int launch_planned(vt_volume* v, const TilePlan& plan, const AffineParams& p, const Orientation& ori, float* d_out, size_t n_out)
 {
     if (plan.kind == 8) {
-        if (!*ori.quad_slot) return fail(VT_EINVAL, "internal: plane-quad copy missing");
+        float* const srcq = (p.flags & (1 << 19)) ? *ori.quade_slot : *ori.quad_slot;
+        if (!srcq) return fail(VT_EINVAL, "internal: plane-quad copy missing");
         // Every other launch of a handle walks the chunk layers from the last to the first: the source planes the previous launch
         // read last are still in the memory-side cache (256 MB, it sees reads and writes alike) when this one starts with them.
         // A schedule only: each workgroup computes what it computed before.  (VT_QUAD_PINGPONG=0: always first to last; 2: always
         // last to first -- the control, which measures like 0.)
         AffineParams q = p;
         if (v->tune.quad_pingpong == 2 || (v->tune.quad_pingpong == 1 && ((v->launch_no++) & 1))) q.flags |= (1 << 20);
-        VT_HIP(launch_affine_quad(plan.cfg, v->interp, *ori.quad_slot, d_out, q, plan.grid, plan.lds_bytes, v->stream));
+        VT_HIP(launch_affine_quad(plan.cfg, v->interp, srcq, d_out, q, plan.grid, plan.lds_bytes, v->stream));
 #ifdef VT_LEGACY
     } else if (plan.kind == 5) {
         if (!*ori.pair_slot) return fail(VT_EINVAL, "internal: plane-pair copy missing");
@@ -691,7 +697,7 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
         plan = TilePlan();
         plan.kind = 0;
         ori = Orientation();
-        ori.src_plain = v->d_src; ori.quad_slot = &v->d_src_q; ori.quad_idx = 0;
+        ori.src_plain = v->d_src; ori.quad_slot = &v->d_src_q; ori.quade_slot = &v->d_src_qe[0]; ori.quad_idx = 0;
 #ifdef VT_LEGACY
         ori.pair_slot = &v->d_src_zp;
 #endif
@@ -1452,6 +1458,7 @@ int vt_volume_destroy(vt_volume_t* v)
     if (v->d_src_t_q) hipFree(v->d_src_t_q);
     if (v->d_src_r_q) hipFree(v->d_src_r_q);
     if (v->d_src_x_q) hipFree(v->d_src_x_q);
+    for (int i = 0; i < 4; ++i) if (v->d_src_qe[i]) hipFree(v->d_src_qe[i]);
     if (v->d_tmp_x) hipFree(v->d_tmp_x);
     if (v->d_scratch_out) cached_free(v->dev, v->d_scratch_out, v->scratch_elems * sizeof(float));
     if (v->d_proj_tmp) hipFree(v->d_proj_tmp);
@@ -1490,7 +1497,8 @@ int vt_volume_info(const vt_volume_t* v, vt_volume_info_t* info)
                            (v->d_src_r ? (uint64_t)v->D * v->W * v->Pr * sizeof(float) : 0) +
                            (v->d_src_x ? (uint64_t)v->W * v->H * v->Px * sizeof(float) : 0) +
                            (v->d_tmp_x ? (uint64_t)v->tmp_x_elems * sizeof(float) : 0) +
-                           v->quad_bytes[0] + v->quad_bytes[1] + v->quad_bytes[2] + v->quad_bytes[3];
+                           v->quad_bytes[0] + v->quad_bytes[1] + v->quad_bytes[2] + v->quad_bytes[3] +
+                           v->quade_bytes[0] + v->quade_bytes[1] + v->quade_bytes[2] + v->quade_bytes[3];
 #ifdef VT_LEGACY
     info->resident_bytes += (v->d_src_zp ? (uint64_t)((v->D + 1) / 2) * v->H * v->P2 * sizeof(float) : 0) +
                             (v->d_src_t_zp ? (uint64_t)((v->H + 1) / 2) * v->D * v->P2 * sizeof(float) : 0) +

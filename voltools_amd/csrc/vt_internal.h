@@ -217,6 +217,7 @@ void quad_config(int idx, int* th, int* tw, int* nt);
 int quad_blocks_per_cu(int cfg, int interp, int lds_bytes, bool zid = false);
 hipError_t init_quad_kernels();
 hipError_t launch_relayout_zquad(const float* src, float* dst, int D, int H, int W, int P, int Pq, hipStream_t stream);
+hipError_t launch_relayout_zquad_fir(const float* src, float* dst, int D, int H, int W, int P, int Pq, bool simple, hipStream_t stream);
 hipError_t launch_affine_quad(int cfg, int interp, const float* srcq, float* out, const AffineParams& p,
                               int grid, int lds_bytes, hipStream_t stream);
 // lane-block kernel for general matrices (vt_kernels_block.hip)

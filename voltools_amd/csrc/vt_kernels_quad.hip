@@ -73,6 +73,47 @@ hipError_t launch_relayout_zquad(const float* src, float* dst, int D, int H, int
     return hipGetLastError();
 }
 
+// Round 4: the plane-quad copy of the Z-CONVOLVED volume, e[z] = w0 c[z-1] + w1 c[z] + w2 c[z+1] with the cubic B-spline weights of
+// fraction 0 (1/6, 2/3, 1/6; the fourth is exactly 0) and zero border.  A cubic launch whose axis-0 offset is an integer -- every rotation
+// about axis 0, every in-plane map: the README sweep -- weighs its four tap planes with exactly these numbers, whatever the matrix, so
+// the axis-0 part of its 64-tap sum can be formed ONCE per volume: output plane d is then the in-plane 16-tap interpolation of plane
+// d + zoff of this copy (KIND 4 below: no carried partials, no history quad, 16-plane chunks -- the trilinear KIND 3's structure with
+// cubic in-plane taps).  Same 64 products as cubicTex3D (helper_interpolation.h:8-40), summed z first instead of x first.
+__global__ __launch_bounds__(256) void relayout_zquad_fir(const float* __restrict__ src, float* __restrict__ dst,
+                                                           int D, int H, int W, int P, int Pq, int simple)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    const int qq = blockIdx.z;
+    if (x >= W) return;
+    const int z0 = 4 * qq;
+    const int64_t plane = (int64_t)H * P;
+    const float* s = src + ((int64_t)z0 * H + y) * P + x;
+    float wz[4];
+    if (simple) cubic_weights<true>(0.0f, wz); else cubic_weights<false>(0.0f, wz);
+    float c[6];                                   // planes z0 - 1 .. z0 + 4
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int z = z0 - 1 + k;
+        c[k] = (z >= 0 && z < D) ? s[(int64_t)(k - 1) * plane] : 0.0f;
+    }
+    v4f v;
+    // the association of the marching kernel's axis-0 combination (zcombine): w0 first, then two FMAs
+    v.x = fmaf(wz[2], c[2], fmaf(wz[1], c[1], wz[0] * c[0]));
+    v.y = (z0 + 1 < D) ? fmaf(wz[2], c[3], fmaf(wz[1], c[2], wz[0] * c[1])) : 0.0f;
+    v.z = (z0 + 2 < D) ? fmaf(wz[2], c[4], fmaf(wz[1], c[3], wz[0] * c[2])) : 0.0f;
+    v.w = (z0 + 3 < D) ? fmaf(wz[2], c[5], fmaf(wz[1], c[4], wz[0] * c[3])) : 0.0f;
+    *reinterpret_cast<v4f*>(dst + ((int64_t)qq * H + y) * Pq + 4 * (int64_t)x) = v;
+}
+
+hipError_t launch_relayout_zquad_fir(const float* src, float* dst, int D, int H, int W, int P, int Pq, bool simple, hipStream_t stream)
+{
+    const dim3 grid((W + 255) / 256, H, (D + 3) / 4);
+    if (grid.y > 65535 || grid.z > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(relayout_zquad_fir, grid, dim3(256), 0, stream, src, dst, D, H, W, P, Pq, simple ? 1 : 0);
+    return hipGetLastError();
+}
+
 __device__ __forceinline__ int floordiv4(int a) { return a >> 2; }           // arithmetic shift = floor division
 
 // One output column (all planes of a chunk at one in-plane pixel) gathered straight from the quad copy -- element (z, y, x)
@@ -81,7 +122,7 @@ template <int KIND>
 __device__ __forceinline__ void quad_gather_column(const float* __restrict__ srcq, float* __restrict__ out, const AffineParams& p, int64_t oo,
                                                 int d_begin, int d_end, bool in_yx, int gy0, int gx0, float fy, float fx)
 {
-    constexpr bool CUBIC = KIND == 1 || KIND == 2;
+    constexpr bool CUBIC = KIND == 1 || KIND == 2 || KIND == 4;
     const bool keep = (p.flags & VT_KEEP_OUTSIDE) != 0;
     auto fetch = [&](int z, int y, int x) -> float {
         if ((unsigned)z < (unsigned)p.sD && (unsigned)y < (unsigned)p.sH && (unsigned)x < (unsigned)p.sW)
@@ -89,7 +130,9 @@ __device__ __forceinline__ void quad_gather_column(const float* __restrict__ src
         return 0.f;
     };
     float wx[4] = {0.f, 0.f, 0.f, 0.f}, wy[4] = {0.f, 0.f, 0.f, 0.f}, wz[4] = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (CUBIC) { cubic_weights<KIND == 2>(fx, wx); cubic_weights<KIND == 2>(fy, wy); cubic_weights<KIND == 2>(p.fz, wz); }
+    if constexpr (KIND == 4) {
+        if (p.flags & (1 << 18)) { cubic_weights<true>(fx, wx); cubic_weights<true>(fy, wy); } else { cubic_weights<false>(fx, wx); cubic_weights<false>(fy, wy); }
+    } else if constexpr (CUBIC) { cubic_weights<KIND == 2>(fx, wx); cubic_weights<KIND == 2>(fy, wy); cubic_weights<KIND == 2>(p.fz, wz); }
     for (int d = d_begin; d < d_end; ++d) {
         const double ez = (double)d + p.m[3];
         const bool inside = in_yx && (ez >= p.vlo[0]) && (ez < p.vhi[0]);
@@ -106,6 +149,20 @@ __device__ __forceinline__ void quad_gather_column(const float* __restrict__ src
                     pl[c] = fmaf(fy, x1 - x0, x0);
                 }
                 val = fmaf(p.fz, pl[1] - pl[0], pl[0]);
+            } else if constexpr (KIND == 4) {
+                // the z-convolved copy: one plane, 16 in-plane taps
+                const int z = d + p.zoff;
+                float accy = 0.f;
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    const int y = gy0 - 1 + bb;
+                    float accx = wx[0] * fetch(z, y, gx0 - 1);
+                    accx = fmaf(wx[1], fetch(z, y, gx0), accx);
+                    accx = fmaf(wx[2], fetch(z, y, gx0 + 1), accx);
+                    accx = fmaf(wx[3], fetch(z, y, gx0 + 2), accx);
+                    accy = fmaf(wy[bb], accx, accy);
+                }
+                val = accy;
             } else {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -147,15 +204,17 @@ __device__ __forceinline__ int quad_pos_to_lane(int pos)
 }
 
 template <int KIND, int TH, int TW, int NT>
-__global__ __launch_bounds__(NT) void affine_march4(const float* __restrict__ srcq, float* __restrict__ out, const AffineParams p)
+__global__ __launch_bounds__(NT, (KIND == 4 && TH * TW == 2 * NT) ? 4 : 1) void affine_march4(const float* __restrict__ srcq, float* __restrict__ out, const AffineParams p)
 {
     static_assert(NT % TW == 0 && TH % (NT / TW) == 0 && NT % 64 == 0 && 64 % TW == 0, "tile/thread mapping");
-    constexpr bool CUBIC = KIND == 1 || KIND == 2;
-    constexpr bool ZID = KIND == 3;               // trilinear, integer axis-0 offset: one tap plane per output plane
-    constexpr int HALO = CUBIC ? 1 : 0;
+    constexpr bool CUBIC = KIND == 1 || KIND == 2 || KIND == 4;      // in-plane stencil: 4 x 4 (else 2 x 2)
+    constexpr bool ZID = KIND == 3 || KIND == 4;  // integer axis-0 offset: ONE tap plane per output plane (KIND 3: trilinear, the other plane has
+                                                  // weight 0; KIND 4: cubic on the z-convolved copy, relayout_zquad_fir)
+    constexpr int HALO = CUBIC ? 1 : 0;           // in-plane halo
+    constexpr int ZH = ZID ? 0 : HALO;            // axis-0 halo
     constexpr int NR = 2 + 2 * HALO;              // tap rows (and columns) per pixel
-    constexpr int NC = 2 * HALO + 1;              // carried in-plane partials per pixel (unused for ZID)
-    constexpr int ZNEW = ZID ? 0 : 1;             // the newest tap plane of output d is d + zoff + HALO + ZNEW
+    constexpr int NC = 2 * ZH + 1;                // carried in-plane partials per pixel (unused for ZID)
+    constexpr int ZNEW = ZID ? 0 : 1;             // the newest tap plane of output d is d + zoff + ZH + ZNEW
     constexpr int RP = NT / TW;
     constexpr int NPIX = TH / RP;
     constexpr int NSTORE = 4 * NPIX;              // store instructions of a full step (one per pixel and plane)
@@ -229,8 +288,16 @@ __global__ __launch_bounds__(NT) void affine_march4(const float* __restrict__ sr
         return;
     }
 
-    const int o1 = (int)floor(lo[1]) - HALO;
-    const int o2 = (int)floor(lo[2]) - HALO;     // every position is its own 16-byte vector: no alignment of the origin
+    // tile-uniform, but float64 -> int conversion is a vector instruction: without the explicit move both floors sit in vector registers
+    // for the whole kernel (the compiler drops __builtin_amdgcn_readfirstlane of a value it knows to be uniform)
+    int o1, o2;
+    {
+        const int f1 = (int)floor(lo[1]), f2 = (int)floor(lo[2]);
+        asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(o1) : "v"(f1));
+        asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(o2) : "v"(f2));
+        o1 -= HALO;
+        o2 -= HALO;                               // every position is its own 16-byte vector: no alignment of the origin
+    }
 
     // ---- per-pixel tap geometry ----
     int iy[NPIX], ix[NPIX];
@@ -249,7 +316,10 @@ __global__ __launch_bounds__(NT) void affine_march4(const float* __restrict__ sr
         fx[px] = (float)(sx - fxd);
         iy[px] = (int)fyd;
         ix[px] = (int)fxd;
-        if constexpr (CUBIC) { cubic_weights<KIND == 2>(fy[px], wy[px]); cubic_weights<KIND == 2>(fx[px], wx[px]); }
+        if constexpr (KIND == 4) {
+            if (p.flags & (1 << 18)) { cubic_weights<true>(fy[px], wy[px]); cubic_weights<true>(fx[px], wx[px]); }
+            else { cubic_weights<false>(fy[px], wy[px]); cubic_weights<false>(fx[px], wx[px]); }
+        } else if constexpr (CUBIC) { cubic_weights<KIND == 2>(fy[px], wy[px]); cubic_weights<KIND == 2>(fx[px], wx[px]); }
         else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) { wy[px][k] = 0.f; wx[px][k] = 0.f; }
@@ -409,7 +479,7 @@ __global__ __launch_bounds__(NT) void affine_march4(const float* __restrict__ sr
     const int quad_bytes = p.sH * p.sPq * 4;      // bytes of one resident quad-plane, < 2^31 (host-checked)
     const int nquads_res = (p.sD + 3) >> 2;
     // first / last source plane any output of the chunk taps, and the quads holding them
-    const int plane_first = d_begin + p.zoff - HALO, plane_last = d_end - 1 + p.zoff + HALO + ZNEW;
+    const int plane_first = d_begin + p.zoff - ZH, plane_last = d_end - 1 + p.zoff + ZH + ZNEW;
     const int Q0 = floordiv4(plane_first), QN = floordiv4(plane_last);
     const int Q_base = max(0, min(Q0, nquads_res - 1));
     // source: one descriptor for the chunk, based at the first resident quad it touches; the quad is selected with the scalar offset
@@ -421,9 +491,9 @@ __global__ __launch_bounds__(NT) void affine_march4(const float* __restrict__ sr
     const int oplane_bytes = (int)(ostride * 4);  // (d_end - d_begin) * oplane_bytes < 2^31 (host-checked)
     const float fz = p.fz;
     float wz[4] = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (CUBIC) cubic_weights<KIND == 2>(fz, wz);
-    // steps whose four outputs all belong to the chunk: quads Qf0 .. Qf1 (output d's newest tap plane is d + zoff + HALO + 1)
-    const int tap_new = p.zoff + HALO + ZNEW;
+    if constexpr (CUBIC && !ZID) cubic_weights<KIND == 2>(fz, wz);
+    // steps whose four outputs all belong to the chunk: quads Qf0 .. Qf1 (output d's newest tap plane is d + zoff + ZH + ZNEW)
+    const int tap_new = p.zoff + ZH + ZNEW;
     const int Qf0 = floordiv4(d_begin + tap_new + 3), Qf1 = floordiv4(d_end - 4 + tap_new);
     const bool nt_stores = (p.flags & (1 << 28)) != 0;       // streaming (nontemporal) output stores, chosen by the planner
     const bool tile_fast = all_valid && (h0 + TH <= p.oH) && (w0 + TW <= p.oW);
@@ -612,6 +682,7 @@ static quad_fn pick_quad(int kind)
         case 0: return affine_march4<0, TH, TW, NT>;
         case 1: return affine_march4<1, TH, TW, NT>;
         case 3: return affine_march4<3, TH, TW, NT>;
+        case 4: return affine_march4<4, TH, TW, NT>;
         default: return affine_march4<2, TH, TW, NT>;
     }
 }
@@ -630,7 +701,7 @@ static quad_fn quad_entry(int cfg, int kind)
 hipError_t init_quad_kernels()
 {
     for (int cfg = 0; cfg < quad_config_count(); ++cfg)
-        for (int kind = 0; kind < 4; ++kind) {
+        for (int kind = 0; kind < 5; ++kind) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(quad_entry(cfg, kind)),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
@@ -644,7 +715,7 @@ int quad_blocks_per_cu(int cfg, int interp, int lds_bytes, bool zid)
 {
     static std::mutex mu;
     static std::unordered_map<uint64_t, int> cache;
-    const int kind = (zid && interp_kind(interp) == 0) ? 3 : interp_kind(interp);
+    const int kind = zid ? (interp_kind(interp) == 0 ? 3 : 4) : interp_kind(interp);
     const uint64_t key = ((uint64_t)cfg << 34) | ((uint64_t)kind << 32) | (uint32_t)lds_bytes;
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(key);
@@ -662,8 +733,11 @@ int quad_blocks_per_cu(int cfg, int interp, int lds_bytes, bool zid)
 hipError_t launch_affine_quad(int cfg, int interp, const float* srcq, float* out, const AffineParams& p,
                               int grid, int lds_bytes, hipStream_t stream)
 {
-    const bool zid = (p.flags & (1 << 25)) != 0 && interp_kind(interp) == 0;      // set by plan_quad when fz == 0 exactly
-    quad_fn fn = quad_entry(cfg, zid ? 3 : interp_kind(interp));
+    // integer axis-0 offset (set by plan_quad when fz == 0 exactly): bit 25 = trilinear on one tap plane (KIND 3), bit 19 = cubic on the
+    // z-convolved copy (KIND 4; bit 18 selects the `_simple` weight formula)
+    const int ik = interp_kind(interp);
+    const int kind = ((p.flags & (1 << 25)) && ik == 0) ? 3 : (((p.flags & (1 << 19)) && ik != 0) ? 4 : ik);
+    quad_fn fn = quad_entry(cfg, kind);
     const dim3 g = (p.flags & (1 << 29)) ? dim3((unsigned)(p.nTh * p.nTw), (unsigned)p.nTd) : dim3((unsigned)grid);
     hipLaunchKernelGGL(fn, g, dim3(kQuad[cfg].nt), lds_bytes, stream, srcq, out, p);
     return hipGetLastError();

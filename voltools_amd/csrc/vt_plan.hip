@@ -342,7 +342,10 @@ bool plan_quad(PlanCtx& c)
     TilePlan* plan = c.plan;
     if (!c.zsep || (c.flags & (VT_NO_MARCH | VT_NO_QUAD | VT_NO_ZPAIR))) return false;
     if (v->H > 65535 || (v->D + 3) / 4 > 65535) return false;      // relayout_zquad's grid (y = rows, z = quads): never plan what cannot be built
-    const int halo = c.cubic ? 1 : 0;
+    // cubic with an integer axis-0 offset (every rotation about axis 0, every in-plane map): the four tap planes' weights are the constants
+    // (1/6, 2/3, 1/6, 0), so the launch samples the z-convolved plane-quad copy with ONE tap plane per output plane (KIND 4)
+    const bool zfir = c.cubic && (float)(c.m[3] - std::floor(c.m[3])) == 0.0f && v->tune.quad_zfir != 0;
+    const int halo = (c.cubic && !zfir) ? 1 : 0;                  // axis-0 halo of the launch
     const int Wq = (v->W + 1 + 7) & ~7;                    // positions per quad-row: >= one zero position, rows of whole 128-byte lines
     const int64_t quad_bytes = (int64_t)v->H * Wq * 16;
     if (quad_bytes >= 0x7fffffffLL) return false;
@@ -364,6 +367,12 @@ bool plan_quad(PlanCtx& c)
     // trilinear with an integer axis-0 offset (every rotation about axis 0): one tap plane per output plane, no history quad
     const bool zid = !c.cubic && p->fz == 0.0f && v->tune.quad_zid != 0;
     if (zid) p->flags |= (1 << 25);
+    if (zfir && p->fz == 0.0f) {
+        p->flags |= (1 << 19);
+        if (v->interp == VT_BSPLINE_SIMPLE || v->interp == VT_FILT_BSPLINE_SIMPLE) p->flags |= (1 << 18);
+    }
+    const bool zfir_on = (p->flags & (1 << 19)) != 0;
+    const bool one_plane = zid || zfir_on;
     const int64_t inplane = (int64_t)p->nTh * p->nTw;
     // chunk depth: every chunk pays one quad step beyond its own planes (history of the first outputs), so chunks are deeper than
     // the plain kernels' -- but short-lived workgroups keep the write stream compact (tools/probes/pattern_probe.hip).
@@ -375,8 +384,11 @@ bool plan_quad(PlanCtx& c)
     // integer-offset trilinear: no history quad, so short chunks cost only their set-up; [measured, tools/r3_quad_ab.sh zid -> profiles/r03_ab_1_zid.txt] 1024^3: 1.476 ms at
     // 16 planes, 1.509 at 24, 1.518 at 32, 1.568 at 48, 1.595 at 64 (the copy structure alone behaves the same: front_probe);
     // 512^3 (variants in one process): 0.1961 at 24, 0.1979 at 16, 0.1992 at 32 -- within the handle-to-handle spread; decided per process below
-    if (zid) target_dch = 16;       // 512^3, one process per variant (profiles/r03_process_ab.txt): 0.1896 ms at 16, 0.1911 at 20, 0.1922 at 24, 0.1953 at 32
-    if (zid && v->tune.zid_dch > 0) target_dch = v->tune.zid_dch;
+    // (KIND 4, cubic on the z-convolved copy, keeps the cubic depth: its set-up -- the row-span table -- is the expensive one.  512^3 filt_bspline, one
+    // process per variant: 0.2495 ms at 16 planes, 0.2047 at 32, 0.1975 at 64, 0.2103 at 128; the four-plane kernel 0.2046)
+    if (zfir_on && (int64_t)v->H * v->W > 512 * 512) target_dch = 32;      // 1024^3 filt_bspline: 1.563 ms at 64 planes, 1.527 at 32 (four-plane kernel: 1.594)
+    if (zid) target_dch = 16;             // 512^3, one process per variant (profiles/r03_process_ab.txt): 0.1896 ms at 16, 0.1911 at 20, 0.1922 at 24, 0.1953 at 32
+    if (one_plane && v->tune.zid_dch > 0) target_dch = v->tune.zid_dch;
     if (v->tune.dch > 0) target_dch = std::max(4, v->tune.dch);
     int64_t nchunks = std::max<int64_t>(1, (v->oD + target_dch - 1) / target_dch);
     // small volumes: shorter chunks until the launch has ~4 workgroups per CU, not below 8 planes per chunk
@@ -385,7 +397,7 @@ bool plan_quad(PlanCtx& c)
     // scalar byte offsets: source quads of a chunk from its first quad, output planes from its first plane (31 bits each)
     const int64_t n_addr = std::max(((int64_t)(v->oD / 4 + 4) * quad_bytes) / 0x60000000LL + 1, ((int64_t)v->oD * max_stride * 4) / 0x60000000LL + 1);
     nchunks = std::max<int64_t>(nchunks, n_addr);
-    plan->blocks_per_cu = quad_blocks_per_cu(plan->cfg, v->interp, plan->lds_bytes, zid);
+    plan->blocks_per_cu = quad_blocks_per_cu(plan->cfg, v->interp, plan->lds_bytes, one_plane);
     int dch = (int)((v->oD + nchunks - 1) / nchunks);
     dch = (dch + 3) & ~3;
     // chunk boundaries at c*dch + dshift: the first tap plane of every chunk but the first, d_begin + zoff - halo, is then the
