@@ -58,8 +58,10 @@ enum vt_flags {
     VT_ONESHOT_EDGE_SCIPY = 4096, /* vt_affine_oneshot only: build the temporary handle with VT_EDGE_SCIPY */
     VT_NO_QUAD = 2048,     /* diagnostic: no plane-quad marching kernel (the plain / plane-pair marching kernels serve instead);
                               VT_NO_ZPAIR disables both interleaved layouts */
-    VT_NO_BLOCK = 8192     /* diagnostic: general matrices use the bounding-box / packed-footprint kernels, not the lane-block
+    VT_NO_BLOCK = 8192,    /* diagnostic: general matrices use the bounding-box / packed-footprint kernels, not the lane-block
                               kernel (VT_NO_PACKED and VT_FORCE_PACKED imply it) */
+    VT_NO_ZFIR = 16384     /* diagnostic: cubic plane-quad launches with an integer axis-0 offset keep the four-tap-plane kernel
+                              instead of sampling the z-convolved copy (also what a call falls back to when that copy does not fit) */
 };
 
 /* flags for vt_volume_create* */

@@ -931,3 +931,42 @@ def test_lane_block_kernel_all_paths(interp, monkeypatch):
             got, info = run_case(vol, m, interp, _native.FORCE_TILED | _native.NO_ZSEP, keep=True, out_init=init)
             assert info.last_kernel == 9
             assert np.abs(got - oracle.affine(vol, m, interp, oracle.KEEP_OUTSIDE, output=init.copy())).max() <= TOL[interp], (shape, mname, 'keep')
+
+
+@pytest.mark.parametrize('interp', ['bspline', 'bspline_simple', 'filt_bspline', 'filt_bspline_simple'])
+@pytest.mark.parametrize('shape', [(70, 66, 72), (5, 40, 48), (33, 130, 70), (2, 64, 64)])
+def test_zconvolved_copy_against_the_oracle_and_the_four_plane_kernel(interp, shape):
+    """Cubic plane-quad launches with an integer axis-0 offset sample the z-convolved copy (KIND 4: the axis-0 weights of such a launch are
+    the constants 1/6, 2/3, 1/6, 0, applied once when the copy is built).  Against the oracle at the family's tolerance, and against the
+    four-tap-plane kernel (VT_NO_ZFIR) on the same handle: same taps, one more rounding of the axis-0 sum, so 2 ulps of the data range.
+    Depths that are not multiples of four, volumes thinner than the stencil, offsets that push the stencil over either end of axis 0, and
+    the copies of the exchanged orientations (rotations about axes 1 / 2)."""
+    vol = rand_vol(shape, 21)
+    c = centre(shape)
+    cases = {
+        'rot33': vt.utils.transform_matrix(rotation=(0, 33, 0), rotation_order='rzxz', center=c),
+        'rot100_up2': vt.utils.transform_matrix(rotation=(0, 100, 0), rotation_order='rzxz', translation=(2, 0.25, -1.5), center=c),
+        'rot33_down3': vt.utils.transform_matrix(rotation=(0, 33, 0), rotation_order='rzxz', translation=(-3, 0, 0), center=c),
+        'shift_inplane': vt.utils.translation_matrix((0, 0.5, -1.25)),
+        'shift_past_the_end': vt.utils.translation_matrix((shape[0] - 1, 0.5, 0.25)),
+        'scale_inplane': vt.utils.transform_matrix(scale=(1.0, 1.2, 0.8), center=c),
+        'rot_axis1': vt.utils.transform_matrix(rotation=(0, 33, 0), rotation_order='sxyz', center=c),
+        'rot_axis2': vt.utils.transform_matrix(rotation=(0, 0, 33), rotation_order='sxyz', center=c),
+    }
+    sv = vt.StaticVolume(vol, interpolation=interp, device='gpu:0')
+    base = sv.info().resident_bytes
+    used_quad = 0
+    for name, m in cases.items():
+        want = oracle.affine(vol, m, interp)
+        got = sv.affine(m, _flags=_native.FORCE_TILED)
+        k = sv.info().last_kernel
+        four = sv.affine(m, _flags=_native.FORCE_TILED | _native.NO_ZFIR)
+        assert sv.info().last_kernel == k, name
+        assert np.abs(got - want).max() <= TOL[interp], (interp, shape, name, k)
+        assert np.abs(four - want).max() <= TOL[interp], (interp, shape, name, k)
+        assert np.abs(got - four).max() <= 4.8e-7 * (3.0 if interp.startswith('filt') else 1.0), (interp, shape, name, k)
+        used_quad += int(k == 8)
+    if used_quad:
+        # both copies of every orientation that marched are accounted for
+        assert sv.info().resident_bytes >= base + 2 * vol.nbytes
+    sv.close()

@@ -710,8 +710,9 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
         if (plan.kind == 0) plan_launch(v, m, pf, &p, &plan);
         const int miss = ensure_secondary_copy(v, plan, p, ori);
         if (miss == 0) break;
-        if (attempt >= 2) return fail(VT_EINVAL, "no kernel family can serve this call (secondary resident copies cannot be built)");
-        deny |= (plan.kind == 8) ? VT_NO_QUAD : VT_NO_ZPAIR;
+        if (attempt >= 3) return fail(VT_EINVAL, "no kernel family can serve this call (secondary resident copies cannot be built)");
+        // (the z-convolved copy of KIND 4 missing: the four-plane kernel on the plain plane-quad copy is next in line)
+        deny |= (plan.kind == 8) ? (((p.flags & (1 << 19)) && !(deny & VT_NO_ZFIR)) ? VT_NO_ZFIR : VT_NO_QUAD) : VT_NO_ZPAIR;
     }
 
     float* d_out = out;

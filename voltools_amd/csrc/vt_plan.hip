@@ -344,7 +344,7 @@ bool plan_quad(PlanCtx& c)
     if (v->H > 65535 || (v->D + 3) / 4 > 65535) return false;      // relayout_zquad's grid (y = rows, z = quads): never plan what cannot be built
     // cubic with an integer axis-0 offset (every rotation about axis 0, every in-plane map): the four tap planes' weights are the constants
     // (1/6, 2/3, 1/6, 0), so the launch samples the z-convolved plane-quad copy with ONE tap plane per output plane (KIND 4)
-    const bool zfir = c.cubic && (float)(c.m[3] - std::floor(c.m[3])) == 0.0f && v->tune.quad_zfir != 0;
+    const bool zfir = c.cubic && (float)(c.m[3] - std::floor(c.m[3])) == 0.0f && v->tune.quad_zfir != 0 && !(c.flags & VT_NO_ZFIR);
     const int halo = (c.cubic && !zfir) ? 1 : 0;                  // axis-0 halo of the launch
     const int Wq = (v->W + 1 + 7) & ~7;                    // positions per quad-row: >= one zero position, rows of whole 128-byte lines
     const int64_t quad_bytes = (int64_t)v->H * Wq * 16;
