@@ -48,6 +48,32 @@ __host__ __device__ __forceinline__ void cubic_weights(float f, float (&w)[4])
 
 // Blocks b and b+8 share an XCD (round-robin dispatch).  Map the blocks of one XCD onto a contiguous
 // range of tile ids (bijective for any grid size).  Placement only affects speed, never results.
+// Wave64 inclusive scans on the DPP network: row_shr inside the 16-lane rows, then row_bcast:15 (rows 1, 3 take the last lane of rows 0, 2)
+// and row_bcast:31 (rows 2, 3 take lane 31) -- six dependent vector operations where a __shfl_up ladder is six LDS round trips
+// (ds_bpermute_b32).  Lanes without a source keep `old` (bound_ctrl off), the operation's identity.  All 64 lanes must be active.
+__device__ __forceinline__ int wave_scan_add(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+    return x;
+}
+__device__ __forceinline__ int wave_scan_max(int x)      // values >= -1
+{
+    x = max(x, __builtin_amdgcn_update_dpp(-1, x, 0x111, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(-1, x, 0x112, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(-1, x, 0x114, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(-1, x, 0x118, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(-1, x, 0x142, 0xa, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(-1, x, 0x143, 0xc, 0xf, false));
+    return x;
+}
+// lane i takes lane i - 1's value, lane 0 takes `first` (wave_shr:1)
+__device__ __forceinline__ int wave_shift_up1(int x, int first) { return __builtin_amdgcn_update_dpp(first, x, 0x138, 0xf, 0xf, false); }
+
 __device__ __forceinline__ int xcd_contiguous(int b, int n)
 {
     const int xcd = b & 7, q = n >> 3, r = n & 7;

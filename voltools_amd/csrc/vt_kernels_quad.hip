@@ -223,6 +223,8 @@ __global__ __launch_bounds__(NT, (KIND == 4 && TH * TW == 2 * NT) ? 4 : 1) void 
     const int tid = threadIdx.x;
 #ifdef VT_EXPERIMENTS      // VT_EXP_NOLOOP + VT_EXP_NOLDS: the launch alone (workgroup dispatch, LDS allocation, argument loads)
     if ((p.flags & (1 << 27)) && (p.flags & (1 << 26))) return;
+    long long stamp[5];                           // VT_EXP_NOLOOP: cycle stamps of the set-up's phases (tools/setup_phases.py)
+    stamp[0] = clock64();
 #endif
     int tw_i, th_i, chunk;
     if (p.flags & (1 << 29)) {
@@ -330,6 +332,9 @@ __global__ __launch_bounds__(NT, (KIND == 4 && TH * TW == 2 * NT) ? 4 : 1) void 
         ob[px] = (int)(((int64_t)j * orow + kw) * 4);           // < 2^31 (host-checked)
     }
 
+#ifdef VT_EXPERIMENTS
+    stamp[1] = clock64();
+#endif
     // ---- row spans of the footprint, packed (one vector per position) ----
     // Exact and integer-only: every pixel taps columns [ix - HALO, ix + HALO + 1] of rows iy - HALO .. iy + HALO + 1 of the
     // box.  Along a pixel row (lanes kw = 0 .. TW-1 of equal j) iy and ix are monotone in kw, so the lanes that tap a given
@@ -364,6 +369,9 @@ __global__ __launch_bounds__(NT, (KIND == 4 && TH * TW == 2 * NT) ? 4 : 1) void 
             }
         }
         __syncthreads();
+#ifdef VT_EXPERIMENTS
+        stamp[2] = clock64();
+#endif
         if (tid < kRowsMax) {
             const int lane = tid;
             const int mn = tab[lane], mx = tab[kRowsMax + lane];
@@ -372,14 +380,9 @@ __global__ __launch_bounds__(NT, (KIND == 4 && TH * TW == 2 * NT) ? 4 : 1) void 
             const int nv = used ? (mx - mn + 1) : 0;
             int first, pad = 0, total;
             {
-                int incl = nv;
-#pragma unroll
-                for (int s2 = 1; s2 < 64; s2 <<= 1) {
-                    const int up = __shfl_up(incl, s2);
-                    if (lane >= s2) incl += up;
-                }
+                const int incl = wave_scan_add(nv);
                 first = incl - nv;
-                total = __shfl(incl, 63);
+                total = __builtin_amdgcn_readlane(incl, 63);
             }
             if (p.row_s >= 0) {
                 // Bank-aware row starts (cubic): row r starts at a slot = x0 + r * S (mod 16), i.e. the image behaves like a box
@@ -396,24 +399,14 @@ __global__ __launch_bounds__(NT, (KIND == 4 && TH * TW == 2 * NT) ? 4 : 1) void 
                 const int S = p.row_s;
                 const int c_r = (x0 + lane * S) & 15;
                 const int end_res = (nv > 0) ? ((c_r + nv) & 15) : 0;            // residue of the position right behind this row
-                int last_used = (nv > 0) ? lane : -1;
-#pragma unroll
-                for (int s2 = 1; s2 < 64; s2 <<= 1) {
-                    const int up = __shfl_up(last_used, s2);
-                    if (lane >= s2) last_used = max(last_used, up);
-                }
-                const int prev_row = __shfl_up(last_used, 1);                    // last row in use strictly before this one (-1: none)
+                const int last_used = wave_scan_max((nv > 0) ? lane : -1);
+                const int prev_row = wave_shift_up1(last_used, -1);              // last row in use strictly before this one (-1: none)
                 int prev_end = __shfl(end_res, max(prev_row, 0));
                 if (lane == 0 || prev_row < 0) prev_end = 0;                     // first row in use: the image starts at position 0
                 const int gap = (nv > 0) ? ((c_r - prev_end) & 15) : 0;
-                int inc2 = gap + nv;
-#pragma unroll
-                for (int s2 = 1; s2 < 64; s2 <<= 1) {
-                    const int up = __shfl_up(inc2, s2);
-                    if (lane >= s2) inc2 += up;
-                }
+                const int inc2 = wave_scan_add(gap + nv);
                 const int first_p = inc2 - nv, pad_p = gap;
-                const int pos = __shfl(inc2, 63);
+                const int pos = __builtin_amdgcn_readlane(inc2, 63);
                 if (((pos + 63) & ~63) * 16 <= p.slot_floats * 4 && pos <= NT * kQuadMaxIt) { first = first_p; pad = pad_p; total = pos; }
             }
             tab[lane] = x0;
@@ -429,6 +422,9 @@ __global__ __launch_bounds__(NT, (KIND == 4 && TH * TW == 2 * NT) ? 4 : 1) void 
             for (; v < last; ++v) vrow[v] = (unsigned char)lane;
         }
         __syncthreads();
+#endif
+#ifdef VT_EXPERIMENTS
+        stamp[3] = clock64();
 #endif
         nvec = tab[2 * kRowsMax];
 #pragma unroll
@@ -504,7 +500,15 @@ __global__ __launch_bounds__(NT, (KIND == 4 && TH * TW == 2 * NT) ? 4 : 1) void 
     constexpr bool no_stores = false, no_loads = false, no_lds = false;
 #endif
 #ifdef VT_EXPERIMENTS
-    if (p.flags & (1 << 27)) { if (nvec == 12345678) out[0] = (float)(voff[0] + q[0][0]); return; }     // VT_EXP_NOLOOP: set-up only
+    if (p.flags & (1 << 27)) {                    // VT_EXP_NOLOOP: set-up only; thread 0 leaves the four phase durations of its workgroup
+        if (nvec == 12345678) out[0] = (float)(voff[0] + q[0][0]);
+        stamp[4] = clock64();
+        if (tid == 0) {
+            const int64_t b = (int64_t)blockIdx.x + (int64_t)gridDim.x * blockIdx.y;
+            for (int k = 0; k < 4; ++k) out[b * 4 + k] = (float)(stamp[k + 1] - stamp[k]);
+        }
+        return;
+    }
 #endif
 
     auto run = [&](auto nit_c) {
