@@ -149,6 +149,12 @@ int vt_volume_finalize(vt_volume_t* vol);
  * send an axis-0-separable matrix to the general-matrix kernels.  (No reference counterpart: diagnostic.) */
 int vt_has_legacy_kernels(void);
 
+/* Free the resident copies the handle built lazily besides its plain one -- per orientation used: the axis-exchanged plain copy, its
+ * plane-quad form and the z-convolved plane-quad form, up to 4x the volume each way round (vt_volume_info.resident_bytes) -- e.g. between
+ * the phases of a job that rotate about different axes, or before another handle needs the memory.  The next call that needs a copy
+ * rebuilds it; results are unchanged.  freed_bytes may be NULL.  (No reference counterpart: the reference keeps one CUDA array per
+ * StaticVolume, volume.py:37-45; cupy's pool serves `free_all_blocks()` for its temporaries.) */
+int vt_volume_release_copies(vt_volume_t* vol, uint64_t* freed_bytes);
 int vt_volume_destroy(vt_volume_t* vol);
 int vt_volume_info(const vt_volume_t* vol, vt_volume_info_t* info);
 int vt_volume_stream(const vt_volume_t* vol, void** hip_stream);   /* the hipStream_t launches go to */

@@ -970,3 +970,31 @@ def test_zconvolved_copy_against_the_oracle_and_the_four_plane_kernel(interp, sh
         # both copies of every orientation that marched are accounted for
         assert sv.info().resident_bytes >= base + 2 * vol.nbytes
     sv.close()
+
+
+@pytest.mark.parametrize('interp', ['linear', 'filt_bspline'])
+def test_release_copies_frees_the_lazy_copies_and_changes_no_result(interp):
+    """`vt_volume_release_copies`: after rotations about all three axes a handle holds the exchanged orientations and their plane-quad forms
+    (several times the volume); releasing them returns the handle to its plain copy, and the next calls rebuild what they need and return
+    the same bits."""
+    shape = (96, 88, 104)
+    vol = rand_vol(shape, 31)
+    c = centre(shape)
+    mats = [vt.utils.transform_matrix(rotation=(0, 33, 0), rotation_order='rzxz', center=c),
+            vt.utils.transform_matrix(rotation=(0, 33, 0), rotation_order='rzxz', translation=(0.5, 0, 0), center=c),
+            vt.utils.transform_matrix(rotation=(0, 33, 0), rotation_order='sxyz', center=c),
+            vt.utils.transform_matrix(rotation=(0, 0, 33), rotation_order='sxyz', center=c),
+            vt.utils.transform_matrix(rotation=(25, -40, 70), rotation_order='sxyz', center=c)]
+    sv = vt.StaticVolume(vol, interpolation=interp, device='gpu:0')
+    base = sv.info().resident_bytes
+    first = [sv.affine(m, _flags=_native.FORCE_TILED) for m in mats]
+    grown = sv.info().resident_bytes
+    assert grown >= base + 3 * vol.nbytes                     # at least the exchanged copies and the plane-quad forms of the sweeps
+    freed = sv.release_copies()
+    assert freed == grown - sv.info().resident_bytes and sv.info().resident_bytes == base
+    assert sv.release_copies() == 0                           # idempotent
+    for m, want in zip(mats, first):
+        assert np.array_equal(sv.affine(m, _flags=_native.FORCE_TILED), want)
+        assert np.abs(want - oracle.affine(vol, m, interp)).max() <= TOL[interp]
+    assert sv.info().resident_bytes == grown
+    sv.close()

@@ -30,7 +30,7 @@ SYMBOLS = [
     'vt_volume_sync', 'vt_volume_set_output_shape', 'vt_volume_affine', 'vt_volume_affine_f64',
     'vt_volume_project', 'vt_volume_project_f64', 'vt_volume_affine_batch',
     'vt_timer_start', 'vt_timer_stop', 'vt_prefilter_inplace', 'vt_affine_oneshot',
-    'vt_last_error', 'vt_version', 'vt_has_legacy_kernels',
+    'vt_last_error', 'vt_version', 'vt_has_legacy_kernels', 'vt_volume_release_copies',
 ]
 
 
@@ -104,6 +104,7 @@ def load():
     L.vt_volume_info.argtypes = [c_void_p, P(VolumeInfo)]
     L.vt_volume_stream.argtypes = [c_void_p, P(c_void_p)]
     L.vt_volume_sync.argtypes = [c_void_p]
+    L.vt_volume_release_copies.argtypes = [c_void_p, P(ctypes.c_uint64)]
     L.vt_volume_set_output_shape.argtypes = [c_void_p, c_int, c_int, c_int]
     L.vt_volume_affine.argtypes = [c_void_p, c_void_p, c_void_p, c_int]
     L.vt_volume_affine_f64.argtypes = [c_void_p, c_void_p, c_void_p, c_int]

@@ -1472,6 +1472,32 @@ int vt_volume_destroy(vt_volume_t* v)
     return 0;
 }
 
+// Free every resident copy a handle has built lazily besides its plain one (exchanged orientations, plane-quad and z-convolved
+// plane-quad forms, the exchanged-result buffer).  They are rebuilt by the first call that needs them; results do not change.
+int vt_volume_release_copies(vt_volume_t* v, uint64_t* freed_bytes)
+{
+    if (!v) return fail(VT_EINVAL, "NULL argument");
+    int rc = use_device(v->dev);
+    if (rc) return rc;
+    vt_volume_info_t before, after;
+    if ((rc = vt_volume_info(v, &before))) return rc;
+    VT_HIP(hipStreamSynchronize(v->stream));      // no launch may still be reading what is freed
+    float** const slots[] = {&v->d_src_t, &v->d_src_x, &v->d_src_r, &v->d_src_q, &v->d_src_t_q, &v->d_src_r_q, &v->d_src_x_q,
+                             &v->d_src_qe[0], &v->d_src_qe[1], &v->d_src_qe[2], &v->d_src_qe[3], &v->d_tmp_x,
+#ifdef VT_LEGACY
+                             &v->d_src_zp, &v->d_src_t_zp, &v->d_src_r_zp, &v->d_src_x_zp,
+#endif
+    };
+    for (float** s : slots)
+        if (*s) { VT_HIP(hipFree(*s)); *s = nullptr; }
+    v->tmp_x_elems = 0;
+    for (int i = 0; i < 4; ++i) { v->quad_bytes[i] = 0; v->quade_bytes[i] = 0; }
+    for (int i = 0; i < 8; ++i) v->copy_retry_in[i] = 0;      // memory was just returned: a copy that did not fit may fit now
+    if ((rc = vt_volume_info(v, &after))) return rc;
+    if (freed_bytes) *freed_bytes = before.resident_bytes - after.resident_bytes;
+    return 0;
+}
+
 int vt_has_legacy_kernels(void)
 {
 #ifdef VT_LEGACY

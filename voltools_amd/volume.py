@@ -77,6 +77,15 @@ class StaticVolume:
         _native.check(self._lib.vt_volume_info(self._handle, ctypes.byref(info)), 'vt_volume_info')
         return info
 
+    def release_copies(self) -> int:
+        """Free the resident copies this volume built lazily besides its plain one (exchanged orientations, plane-quad forms); they are
+        rebuilt on demand.  Returns the bytes freed.  (No reference counterpart: the reference holds one CUDA array, volume.py:37-45.)"""
+        if self.device == 'cpu':
+            return 0
+        freed = ctypes.c_uint64()
+        _native.check(self._lib.vt_volume_release_copies(self._handle, ctypes.byref(freed)), 'vt_volume_release_copies')
+        return int(freed.value)
+
     def synchronize(self) -> None:
         _native.check(self._lib.vt_volume_sync(self._handle), 'vt_volume_sync')
 
