@@ -250,8 +250,11 @@ def main():
     kernel_ms = kernel_ms_total / args.steps
     algo_bytes = 8.0 * nd * n * n                    # 4 B compulsory source read + 4 B store per output voxel (per rank's launch)
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-    # (the README sweep has an integer axis-0 offset: trilinear launches run the one-plane instantiation, KIND 3)
-    kind_code = {'linear': 3 if int(info.last_kernel) == 8 else 0, 'bspline': 1, 'filt_bspline': 1}.get(interp, 2)
+    # (the README sweep has an integer axis-0 offset: on the plane-quad kernel its launches run the one-tap-plane instantiations,
+    #  KIND 3 trilinear / KIND 4 cubic on the z-convolved copy; VT_QUAD_ZFIR=0 keeps the four-plane cubic kernel, KIND 1 / 2)
+    quad = int(info.last_kernel) == 8
+    zfir = quad and os.environ.get('VT_QUAD_ZFIR', '1') != '0'
+    kind_code = 3 if (interp == 'linear' and quad) else 0 if interp == 'linear' else 4 if zfir else 1 if interp in ('bspline', 'filt_bspline') else 2
     kname = {1: f'vt::affine_direct<{kind_code}>', 2: f'vt::affine_tiled<{kind_code}', 3: f'vt::affine_tiled_zsep<{kind_code}',
              4: f'vt::affine_march_zsep<{kind_code}', 5: f'vt::affine_march_zpair<{kind_code}', 8: f'vt::affine_march4<{kind_code}'}.get(int(info.last_kernel), 'vt::affine')
     case = {(512, 'filt_bspline'): 'bench', (1024, 'filt_bspline'): 'sweep1024', (512, 'linear'): 'linear512', (1024, 'linear'): 'linear1024'}.get((n, interp))
