@@ -32,6 +32,8 @@
 //     30 degrees: conflicts by construction).  [model, tools/quad_conflict_sim.py] with bank-aware row starts: 1.67 -> 1.12
 //     LDS cycles per read at 15 degrees, 2.0 -> 1.31 at 20.  The store of a wave still covers the same two 128-byte row segments.
 #include "vt_internal.h"
+#include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <unordered_map>
 #include "vt_device.h"
@@ -204,6 +206,8 @@ __device__ __forceinline__ int quad_pos_to_lane(int pos)
 }
 
 template <int KIND, int TH, int TW, int NT>
+// (KIND 3 with 512 threads is held to three workgroups per CU by its 100+ scalar registers -- 7 waves per SIMD; capped at 96 it runs four
+// and is 0.7 % slower: 512^3 0.1748 against 0.1731 ms, 1024^3 1.497 against 1.486, one process per variant)
 __global__ __launch_bounds__(NT, (KIND == 4 && TH * TW == 2 * NT) ? 4 : 1) void affine_march4(const float* __restrict__ srcq, float* __restrict__ out, const AffineParams p)
 {
     static_assert(NT % TW == 0 && TH % (NT / TW) == 0 && NT % 64 == 0 && 64 % TW == 0, "tile/thread mapping");
@@ -730,6 +734,9 @@ int quad_blocks_per_cu(int cfg, int interp, int lds_bytes, bool zid)
         (void)hipGetLastError();
         n = 1;
     }
+    if (std::getenv("VT_DEBUG_ALLOC"))
+        std::fprintf(stderr, "[vt] plane-quad kernel kind %d, tile %d x %d, %d threads, %d bytes of LDS: %d workgroups per CU\n", kind, kQuad[cfg].th,
+                     kQuad[cfg].tw, kQuad[cfg].nt, lds_bytes, n);
     cache.emplace(key, n);
     return n;
 }
