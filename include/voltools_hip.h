@@ -60,8 +60,9 @@ enum vt_flags {
                               VT_NO_ZPAIR disables both interleaved layouts */
     VT_NO_BLOCK = 8192,    /* diagnostic: general matrices use the bounding-box / packed-footprint kernels, not the lane-block
                               kernel (VT_NO_PACKED and VT_FORCE_PACKED imply it) */
-    VT_NO_ZFIR = 16384     /* diagnostic: cubic plane-quad launches with an integer axis-0 offset keep the four-tap-plane kernel
+    VT_NO_ZFIR = 16384,    /* diagnostic: cubic plane-quad launches with an integer axis-0 offset keep the four-tap-plane kernel
                               instead of sampling the z-convolved copy (also what a call falls back to when that copy does not fit) */
+    VT_NO_REORIENT = 32768 /* diagnostic: general matrices always sample the plain resident copy, never an axis-permuted one */
 };
 
 /* flags for vt_volume_create* */

@@ -998,3 +998,67 @@ def test_release_copies_frees_the_lazy_copies_and_changes_no_result(interp):
         assert np.abs(want - oracle.affine(vol, m, interp)).max() <= TOL[interp]
     assert sv.info().resident_bytes == grown
     sv.close()
+
+
+@pytest.mark.parametrize('interp', ['linear', 'bspline', 'filt_bspline_simple'])
+def test_general_matrices_on_the_copy_whose_rows_follow_the_output_w_axis(interp):
+    """General matrices whose output w direction follows source axis 0 / 1 sample the axis-permuted resident copies (`try_general_reorient`:
+    same taps, the source side of the launch permuted).  Every general-matrix kernel family against the oracle at the family's tolerance
+    and against the same family on the plain copy (`VT_NO_REORIENT`): the two differ by the order of the per-axis sums only."""
+    shape = (70, 66, 72)
+    vol = rand_vol(shape, 41)
+    c = centre(shape)
+    cases = {
+        'w_follows_axis0': vt.utils.transform_matrix(rotation=(20, 75, 10), rotation_order='sxyz', center=c),
+        'w_follows_axis1': vt.utils.transform_matrix(rotation=(80, 10, 15), rotation_order='sxyz', center=c),
+        'w_follows_axis0_affine': vt.utils.transform_matrix(rotation=(-30, 110, 5), scale=(1.1, 0.9, 1.2), translation=(1.5, -2, 0.75), rotation_order='sxyz', center=c),
+        'w_follows_axis1_mirror': vt.utils.transform_matrix(rotation=(-100, 12, 7), scale=(1.0, -1.0, 1.0), rotation_order='sxyz', center=c),
+    }
+    FT = _native.FORCE_TILED
+    families = (FT, FT | _native.NO_BLOCK, FT | _native.NO_PACKED, FT | _native.FORCE_PACKED)
+    sv = vt.StaticVolume(vol, interpolation=interp, device='gpu:0')
+    base = sv.info().resident_bytes
+    for name, m in cases.items():
+        m64 = np.asarray(m, np.float64)
+        follows = int(np.argmax(np.abs(m64[:3, 2])))
+        assert follows == (0 if 'axis0' in name else 1), name
+        want = oracle.affine(vol, m, interp)
+        for flags in families:
+            got = sv.affine(m, _flags=flags)
+            k = sv.info().last_kernel
+            assert k in (2, 6, 9)
+            plain = sv.affine(m, _flags=flags | _native.NO_REORIENT)
+            assert np.abs(got - want).max() <= TOL[interp], (interp, name, flags, k)
+            assert np.abs(plain - want).max() <= TOL[interp], (interp, name, flags, k)
+            assert np.abs(got - plain).max() <= 2 * TOL[interp]
+    assert sv.info().resident_bytes >= base + 2 * vol.nbytes          # both permuted copies were built
+    sv.close()
+
+
+def test_reoriented_copies_are_built_at_the_fourth_request_only():
+    """Without VT_FORCE_TILED a handle builds an axis-permuted copy when the FOURTH general matrix asks for it (a one-shot handle never
+    pays the transpose pass), only from 192^3 outputs on, and the result is the same array either way to the family's tolerance."""
+    shape = (200, 192, 208)
+    vol = rand_vol(shape, 43)
+    c = centre(shape)
+    m = vt.utils.transform_matrix(rotation=(20, 75, 10), rotation_order='sxyz', center=c)
+    sv = vt.StaticVolume(vol, interpolation='linear', device='gpu:0')
+    base = sv.info().resident_bytes
+    outs = []
+    for i in range(5):
+        outs.append(sv.affine(m))
+        grown = sv.info().resident_bytes > base
+        assert grown == (i >= 3), i
+    assert np.abs(outs[0] - outs[4]).max() <= 2 * TOL['linear']
+    assert np.array_equal(outs[3], outs[4])
+    want = oracle.affine_ex(vol, np.asarray(m, np.float64), 'linear', (8,) + shape[1:], out_plane0=90)     # output planes 90..97
+    assert np.abs(outs[4][90:98] - want).max() <= TOL['linear']
+    assert np.abs(outs[0][90:98] - want).max() <= TOL['linear']
+    small = vt.StaticVolume(vol[:100, :100, :100].copy(), interpolation='linear', device='gpu:0')
+    b0 = small.info().resident_bytes
+    ms = vt.utils.transform_matrix(rotation=(20, 75, 10), rotation_order='sxyz', center=centre((100, 100, 100)))
+    for _ in range(6):
+        small.affine(ms)
+    assert small.info().resident_bytes == b0
+    small.close()
+    sv.close()

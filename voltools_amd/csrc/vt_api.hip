@@ -541,6 +541,63 @@ int try_inplane_transposed(vt_volume* v, const double m[12], int flags, size_t n
     return 0;
 }
 
+// General matrices (none of the forms above): the general-matrix kernels stage source ROWS -- runs along the resident copy's fastest axis --
+// and their lanes walk along the output's w axis.  Where w follows source axis 0 or 1 more closely than axis 2, the rows a tile touches
+// are many and short on the plain copy (partly used cache lines, short staged vectors, lanes of a wave scattered over LDS rows); sampled
+// from the copy whose FASTEST axis is the one w follows ([x][y][z] of the axis-2 exchange, [z][x][y] of the in-plane transposition: the
+// copies the marching kernels use) the same launch has long rows.  Only the source side changes -- the matrix rows are permuted with the
+// copy's axes, the output is written as usual, the skirt test's chains are per row and unchanged.  [measured, 512^3, the reference's 100
+// random rotations, tools/general_reorient_probe.py] trilinear 0.449 -> 0.426 ms, cubic 1.004 -> 0.956 (best of the three copies per
+// matrix: 0.422 / 0.949).  A copy is built at the handle's FOURTH call that asks for it: a handle used once or twice (vt_affine_oneshot)
+// never pays a transpose pass for a few per cent of one launch.
+int try_general_reorient(vt_volume* v, const double m[12], int flags, size_t n_out, AffineParams* p, TilePlan* plan, Orientation* ori)
+{
+    if ((flags & (VT_FORCE_DIRECT | VT_NO_REORIENT)) || v->tune.reorient == 0) return 0;
+    if (n_out < (size_t)192 * 192 * 192 && !(flags & VT_FORCE_TILED)) return 0;      // launch-bound sizes: nothing to win
+    // the source axis the output's w direction follows (the plain copy keeps ties and near-ties: no copy, no churn)
+    const double c[3] = {std::fabs(m[2]), std::fabs(m[6]), std::fabs(m[10])};
+    int a = 2;
+    if (c[1] > 1.15 * c[2] && c[1] >= c[0]) a = 1;
+    if (c[0] > 1.15 * c[2] && c[0] > c[1]) a = 0;
+    if (a == 2) return 0;
+    if (a == 0 && !(v->plane0 == 0 && v->out_plane0 == 0 && v->gD == v->D)) return 0;  // slab windows live on axis 0: it stays the slowest
+    float** const slot = (a == 1) ? &v->d_src_r : &v->d_src_x;
+    int* const asked = &v->reorient_asked[a];
+    if (!*slot && ++*asked < ((flags & VT_FORCE_TILED) ? 1 : v->tune.reorient)) return 0;
+    const vt_volume sw = (a == 1) ? planning_view(v, v->D, v->W, v->H, resident_pitch(v->H), v->oD, v->oH, v->oW, true)
+                                  : planning_view(v, v->W, v->H, v->D, resident_pitch(v->D), v->oD, v->oH, v->oW, false);
+    const int pi[3] = {a == 1 ? 0 : 2, a == 1 ? 2 : 1, a == 1 ? 1 : 0};                // source axis of the copy's axis r
+    double ms[12];
+    for (int r = 0; r < 3; ++r)
+        for (int k = 0; k < 4; ++k) ms[4 * r + k] = m[4 * pi[r] + k];
+    AffineParams ps;
+    std::memset(&ps, 0, sizeof(ps));
+    TilePlan plans;
+    plan_launch(&sw, ms, flags, &ps, &plans);
+    if (!(plans.kind == 2 || plans.kind == 6 || plans.kind == 9)) return 0;           // the general-matrix kernels only
+    if (!*slot) {
+        const size_t bytes = (size_t)sw.D * sw.H * sw.P * sizeof(float);
+        if (hipMalloc(reinterpret_cast<void**>(slot), bytes) != hipSuccess) {
+            (void)hipGetLastError();          // no room for another copy: the plain layout serves this matrix
+            *slot = nullptr;
+            *asked = -64;                     // ... and the next 64 requests
+            return 0;
+        }
+        VT_HIP(hipMemsetAsync(*slot, 0, bytes, v->stream));                              // pad columns must be zero
+        if (a == 1) {
+            v->Pr = sw.P;
+            VT_HIP(launch_transpose02(v->d_src, v->d_src_r, v->H, v->D, v->W, v->P, (int64_t)v->H * v->P, v->Pr, (int64_t)v->W * v->Pr, v->stream));
+        } else {
+            v->Px = sw.P;
+            VT_HIP(launch_transpose02(v->d_src, v->d_src_x, v->D, v->H, v->W, (int64_t)v->H * v->P, v->P, (int64_t)v->H * v->Px, v->Px, v->stream));
+        }
+    }
+    *p = ps; *plan = plans;
+    ori->src_plain = *slot;
+    ori->srcD = sw.D; ori->srcH = sw.H; ori->rowW = sw.W; ori->rowP = sw.P;
+    return 0;
+}
+
 void note_launch(vt_volume* v, int kind, const TilePlan& plan, const AffineParams& p, size_t n_out)
 {
     v->last_kernel = kind;
@@ -639,20 +696,20 @@ int launch_planned(vt_volume* v, const TilePlan& plan, const AffineParams& p, co
 #ifdef VT_EXPERIMENTS      // occupancy experiment: fewer resident workgroups per CU through a larger LDS request / a smaller persistent grid
             static const int exp_lds = std::getenv("VT_EXP_BLOCK_LDS") ? std::atoi(std::getenv("VT_EXP_BLOCK_LDS")) : 0;
             static const int exp_grid = std::getenv("VT_EXP_BLOCK_GRID") ? std::atoi(std::getenv("VT_EXP_BLOCK_GRID")) : 0;
-            VT_HIP(launch_affine_block(plan.cfg, plan.th, v->interp, v->d_src, d_out, v->d_zeros, v->d_queue, p, plan.geo, exp_grid > 0 ? exp_grid : plan.grid,
+            VT_HIP(launch_affine_block(plan.cfg, plan.th, v->interp, ori.src_plain, d_out, v->d_zeros, v->d_queue, p, plan.geo, exp_grid > 0 ? exp_grid : plan.grid,
                                        std::max(plan.lds_bytes, exp_lds), v->stream));
 #else
-            VT_HIP(launch_affine_block(plan.cfg, plan.th, v->interp, v->d_src, d_out, v->d_zeros, v->d_queue, p, plan.geo, plan.grid, plan.lds_bytes, v->stream));
+            VT_HIP(launch_affine_block(plan.cfg, plan.th, v->interp, ori.src_plain, d_out, v->d_zeros, v->d_queue, p, plan.geo, plan.grid, plan.lds_bytes, v->stream));
 #endif
         }
         else
-            VT_HIP(launch_affine_packed(plan.cfg, v->interp, v->d_src, d_out, v->d_zeros, v->d_queue, p, plan.geo, plan.grid, plan.lds_bytes, v->stream));
+            VT_HIP(launch_affine_packed(plan.cfg, v->interp, ori.src_plain, d_out, v->d_zeros, v->d_queue, p, plan.geo, plan.grid, plan.lds_bytes, v->stream));
 #ifdef VT_LEGACY
     } else if (plan.kind == 4) {
         VT_HIP(launch_affine_march(plan.cfg, v->interp, ori.src_plain, d_out, p, plan.grid, plan.lds_bytes, v->stream));
 #endif
     } else if (plan.kind >= 2) {
-        VT_HIP(launch_affine_tiled(plan.cfg, v->interp, plan.kind == 3, v->d_src, d_out, v->d_zeros, p, plan.grid, plan.lds_bytes, v->stream));
+        VT_HIP(launch_affine_tiled(plan.cfg, v->interp, plan.kind == 3, ori.src_plain, d_out, v->d_zeros, p, plan.grid, plan.lds_bytes, v->stream));
     } else {
         VT_HIP(launch_affine_direct(v->interp, v->d_src, d_out, p, v->stream));
     }
@@ -707,6 +764,7 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
         if ((rc = try_axis1_exchange(v, m, pf, n_out, &p, &plan, &ori))) return rc;
         if (plan.kind == 0 && (rc = try_axis2_exchange(v, m, pf, n_out, &p, &plan, &ori))) return rc;
         if (plan.kind == 0 && (rc = try_inplane_transposed(v, m, pf, n_out, &p, &plan, &ori))) return rc;
+        if (plan.kind == 0 && (rc = try_general_reorient(v, m, pf, n_out, &p, &plan, &ori))) return rc;
         if (plan.kind == 0) plan_launch(v, m, pf, &p, &plan);
         const int miss = ensure_secondary_copy(v, plan, p, ori);
         if (miss == 0) break;

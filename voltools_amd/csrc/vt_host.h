@@ -30,7 +30,8 @@ struct Tuning {
     bool no_proj_cache = false;    // VT_NO_PROJ_CACHE: every projection recomputes the weighted plane sum (test of the cache)
     int quad_pingpong = 1;         // VT_QUAD_PINGPONG: 1 = every other launch of a handle walks the chunk layers from the last to the first; 0 / 2 = never / always
     int quad_zid = 1;              // VT_QUAD_ZID=0: trilinear launches with fz == 0 keep the two-plane kernel (round-3 A/B)
-    int quad_zfir = 1;             // VT_QUAD_ZFIR=0: cubic launches with fz == 0 keep the four-plane kernel (round-4 A/B: the z-convolved copy)
+int reorient = 4;              // VT_REORIENT: general matrices sample the resident copy whose rows follow the output's w axis, built at the n-th request (0 = never)
+        int quad_zfir = 1;             // VT_QUAD_ZFIR=0: cubic launches with fz == 0 keep the four-plane kernel (round-4 A/B: the z-convolved copy)
     int zid_dch = 0;               // VT_ZID_DCH: chunk depth of the integer-offset trilinear kernel (0 = the trilinear default)
     int quad_nt = -1;              // VT_QUAD_NT: 1 / 0 = nontemporal / plain output stores of the plane-quad kernel, -1 = planner's choice
     bool no_block = false;         // VT_NO_BLOCK_KERNEL: general matrices on the round-1 box / packed kernels
@@ -70,6 +71,7 @@ struct Tuning {
 #endif
         quad_pingpong = num("VT_QUAD_PINGPONG", 1);
         quad_zfir = num("VT_QUAD_ZFIR", 1);
+        reorient = num("VT_REORIENT", 4);
         no_proj_cache = std::getenv("VT_NO_PROJ_CACHE") != nullptr;
         zid_dch = num("VT_ZID_DCH", 0);
         quad_reverse = num("VT_QUAD_REVERSE", -1);
@@ -112,6 +114,7 @@ struct vt_volume {
     size_t quad_bytes[4] = {0, 0, 0, 0};   // allocation sizes of the four quad copies (vt_volume_info)
     float* d_src_qe[4] = {nullptr, nullptr, nullptr, nullptr};   // plane-quad copies of the Z-CONVOLVED volume per orientation (cubic launches with an integer axis-0 offset; vt_kernels_quad.hip: relayout_zquad_fir); lazy
     size_t quade_bytes[4] = {0, 0, 0, 0};
+    int reorient_asked[3] = {0, 0, 0};   // general matrices that asked for the copy whose fastest axis is source axis 0 / 1 (vt_api.hip: try_general_reorient)
     int copy_retry_in[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // calls to go before a quad copy that could not be allocated is attempted again (per orientation; 4..7: the z-convolved ones)
 #ifdef VT_LEGACY
     // plane-pair copies of the four orientations (round 1's cubic marching kernel, kind 5): test build only
