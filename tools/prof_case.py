@@ -20,6 +20,7 @@ ap.add_argument('--axis2', action='store_true', help='rotation by --angle about 
 ap.add_argument('--sweep', type=float, default=0.0, help='README sweep: rotate((0, i, 0)) for i = 0, step, 2 step, ... < 180 instead of one angle')
 ap.add_argument('--general', action='store_true', help='general 3-D rotation (25,-40,70) sxyz instead of in-plane')
 ap.add_argument('--case', default='', help='named matrix from tests/test_gpu_parity.py MATRICES (overrides --angle/--general)')
+ap.add_argument('--random100', action='store_true', help="the 100 random sxyz rotations of the reference's protocol (tests/benchmark.py:52-54), one after the other")
 ap.add_argument('--iters', type=int, default=10)
 ap.add_argument('--flags', type=int, default=0)
 args = ap.parse_args()
@@ -48,7 +49,12 @@ if args.case:
     from test_gpu_parity import MATRICES
     m = MATRICES[args.case]((n, n, n))
 mats = [m]
-if args.sweep > 0:
+if args.random100:
+    rs_ = np.random.RandomState(1)
+    rs_.random_sample(n * n * n) if n < 768 else None
+    mats = [vt.utils.transform_matrix(rotation=r, rotation_order='sxyz', center=np.divide((n, n, n), 2)) for r in rs_.uniform(-180, 180, (100, 3))]
+    args.sweep = 1.0
+if args.sweep > 0 and not args.random100:
     mats = [vt.utils.transform_matrix(rotation=(0, float(a), 0), rotation_order='rzxz', center=c) for a in np.arange(0.0, 180.0, args.sweep)]
 for mm in (mats if args.sweep > 0 else [m] * 3):
     sv.affine(mm, output=out, _flags=args.flags)        # (a sweep runs once untimed: the lazily built resident copies exist afterwards)
