@@ -87,6 +87,7 @@ def test_host_result_pool_reuses_only_released_buffers(monkeypatch):
 
     fake = FakeLib()
     monkeypatch.setattr(_native, 'load', lambda: fake)
+    monkeypatch.setenv('VT_HOST_POOL_MIN_MB', '1')
     pool = _native._HostResultPool()
     shape = (64, 64, 64)
     a = pool.take(shape, 0)

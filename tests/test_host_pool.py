@@ -12,7 +12,7 @@ class _Recorder:
         self.live = {}
 
     def vt_host_register(self, dev, ptr, nbytes):
-        assert ptr.value % 4096 == 0 and nbytes % 4096 == 0, 'registered ranges must be whole pages'
+        assert ptr.value % (2 << 20) == 0 and nbytes % (2 << 20) == 0, 'registered ranges must be whole 2 MiB units (transparent huge pages)'
         for a, n in self.live.items():
             assert ptr.value + nbytes <= a or a + n <= ptr.value, 'registered ranges must not share pages'
         self.live[ptr.value] = nbytes
@@ -27,6 +27,7 @@ def test_pool_buffers_are_page_isolated_and_reused_only_when_released(monkeypatc
     rec = _Recorder()
     monkeypatch.setattr(_native, '_lib', rec)
     monkeypatch.setenv('VT_HOST_POOL_MB', '8')
+    monkeypatch.setenv('VT_HOST_POOL_MIN_MB', '1')
     pool = _native._HostResultPool()
     shape = (64, 64, 80)                                   # 1.25 MiB
     a = pool.take(shape, 0)
@@ -45,7 +46,7 @@ def test_pool_buffers_are_page_isolated_and_reused_only_when_released(monkeypatc
     del d
     big = [pool.take((64, 64, 200), 0) for _ in range(3)]  # 3 x 3.1 MiB
     assert all(x.ctypes.data % 4096 == 0 for x in big)
-    assert sum(rec.live.values()) <= (8 << 20) + (4 << 20)
+    assert sum(rec.live.values()) <= (8 << 20) + (4 << 20)                  # (registered bytes are 2 MiB-granular: 2 x 2 + 4 MiB here)
     assert b.ctypes.data in rec.live and c.ctypes.data in rec.live
     small = pool.take((8, 8, 8), 0)                        # below the pool threshold: a plain array
     assert small.shape == (8, 8, 8)

@@ -235,7 +235,7 @@ class _HostResultPool:
     (tools/pcie_probe.py).  Results therefore come from a small pool of host buffers that stay faulted-in and
     registered with the HIP runtime: a buffer is handed out again once the caller has dropped every array that
     views it (reference count of the backing array back at the pool's own).  Arrays the caller keeps are never reused.
-    Every pooled buffer is page-aligned and owns whole pages (``_page_aligned_floats``).
+    Every pooled buffer is an anonymous mapping of its own, 2 MiB-aligned, whole 2 MiB units (``_page_aligned_backing``).
     ``VT_HOST_POOL=0`` disables the pool; ``VT_HOST_POOL_MB`` caps it (default: a tenth of the machine's memory, between
     4 and 64 GiB -- a loop over 1024^3 one-shot results alternates between two 4-GiB buffers: 94 ms per call with both in the
     pool, 250 ms when one of them is a fresh allocation every time)."""
@@ -249,7 +249,9 @@ class _HostResultPool:
             phys_mb = 0
         default_mb = min(65536, max(4096, phys_mb // 10))
         self.cap = int(os.environ.get('VT_HOST_POOL_MB', str(default_mb))) << 20
-        self.min_bytes = 1 << 20   # small results are not worth a pool slot
+        # small results are not worth a pool slot (and a 2 MiB-granular one): below the library's own pinning threshold (PinnedScope, 8 MiB)
+        # a result is a plain numpy array, copied through the runtime's staging buffers
+        self.min_bytes = int(os.environ.get('VT_HOST_POOL_MIN_MB', '8')) << 20
         # reference count of a backing array that nobody outside the pool refers to, measured by the scan itself
         # (the entry is built inside the call: a local name for the backing array would count as a holder)
         self._idle = self._scan([self._new_entry(1)], 1, calibrate=True)
@@ -269,7 +271,8 @@ class _HostResultPool:
 
     @staticmethod
     def _new_entry(n: int):
-        return _page_aligned_backing(n)[:2] + (n, (n * 4 + _PAGE - 1) // _PAGE * _PAGE)
+        raw, off, reg = _page_aligned_backing(n)
+        return raw, off, n, reg
 
     @staticmethod
     def _view(entry, shape) -> np.ndarray:
@@ -321,20 +324,22 @@ class _HostResultPool:
 
 
 _PAGE = 4096
+_HUGE = 2 << 20          # granularity at which the pool isolates its buffers: the host's transparent huge pages
 
 
 def _page_aligned_backing(n: int):
-    """Backing store for a float32 result of n elements that starts on a page boundary and owns every page it touches:
-    (uint8 array, offset of the first page boundary in it, bytes to register -- a whole number of pages).
-    Registration pins and maps WHOLE pages at the host's own virtual address; a heap array shares its first and last page
-    with its neighbours, so registering it as it stands overlaps whatever else gets pinned on those pages (another pooled
-    buffer, a caller's array during a copy, the runtime's own temporary pin of a pageable transfer) -- and releasing any one
-    of them takes the shared page out of the GPU's page table under the others: a `Memory access fault by GPU` on a
-    page-aligned HOST address at some later copy (the round-1 abort inside vt_volume_create; seen again in round 2 with the
-    runtime's message intact)."""
-    reg = (n * 4 + _PAGE - 1) // _PAGE * _PAGE
-    raw = np.empty(reg + _PAGE, dtype=np.uint8)
-    return raw, (-raw.ctypes.data) % _PAGE, reg
+    """Backing store for a float32 result of n elements: (uint8 array, offset of the registered range in it, bytes to register).
+    Registration pins and maps pages at the host's own virtual address, and releasing ANY pinned range that shares a mapping unit with
+    another takes the shared unit out of the GPU's page table under the other: a `Memory access fault by GPU` on a page-aligned
+    HOST address at some later copy (the round-1 abort inside vt_volume_create; round 2, with the runtime's message intact).  The unit
+    is not always a 4 KiB page: heap arrays of a few MiB sit next to each other inside 2 MiB transparent huge pages, and the runtime's
+    own temporary pin of a pageable transfer (the upload of the next volume, say) covers whole units (round 4: the fault again, one
+    GPU box in three, on a 4.8 MiB result that shared a huge page with the test's input array).  A pooled buffer therefore owns an
+    anonymous mapping of its own, 2 MiB-aligned and a whole number of 2 MiB units: nothing else can live in a unit that gets registered."""
+    import mmap
+    reg = (n * 4 + _HUGE - 1) // _HUGE * _HUGE
+    raw = np.frombuffer(mmap.mmap(-1, reg + _HUGE), dtype=np.uint8)
+    return raw, (-raw.ctypes.data) % _HUGE, reg
 
 
 _host_pool = _HostResultPool()
