@@ -93,6 +93,8 @@ def test_tiled_and_direct_match_oracle(interp, mname, shape):
     if mname in ('rot_axis1', 'rot_axis1_shift', 'rot_axis2', 'rot_axis2_shift'):
         # rotations about axis 1 / 2 march along an axis-exchanged resident copy
         assert 8 in kernels and (not LEGACY or ((4 in kernels) if interp == 'linear' else (5 in kernels and 4 in kernels)))
+    if mname == 'rot_axis2':
+        assert 7 in kernels                          # ... and, with an integer offset along axis 2, the row kernel serves them on the plain copy
     if mname in ('identity', 'shift_int', 'shift_frac', 'rot_inplane45', 'rot_inplane100', 'rot_inplane260'):
         assert 8 in kernels
         if LEGACY:
@@ -1061,4 +1063,53 @@ def test_reoriented_copies_are_built_at_the_fourth_request_only():
         small.affine(ms)
     assert small.info().resident_bytes == b0
     small.close()
+    sv.close()
+
+
+@pytest.mark.parametrize('interp', ALL_INTERPS)
+@pytest.mark.parametrize('shape', [(70, 66, 72), (33, 47, 50), (5, 9, 130), (64, 64, 64)])
+def test_row_kernel_for_maps_that_leave_axis_2_alone(interp, shape):
+    """Kind 7 (vt_kernels_rows.hip): rotations about axis 2 and any (d, h) affine map with an integer axis-2 offset that is a multiple
+    of four.  Against the oracle at the family's tolerance and BIT-IDENTICAL to affine_direct (same chain of operations, the x-sum of the
+    cubic stencil formed once in the x-convolved copy); widths that are no multiple of 64 or 4, offsets that push rows over either end,
+    keep_outside, and the offsets the kernel does not take (fractional, not a multiple of four) going elsewhere."""
+    vol = rand_vol(shape, 51)
+    c = centre(shape)
+    rot = vt.utils.transform_matrix(rotation=(0, 0, 33), rotation_order='sxyz', center=c)
+    cases = {'rot33': (rot, True)}
+    for name, t2, takes in (('rot33_w+8', 8.0, True), ('rot33_w-4', -4.0, True), ('rot33_w+2', 2.0, False), ('rot33_w+0.5', 0.5, False)):
+        m = rot.copy(); m[2, 3] += t2
+        cases[name] = (m, takes)
+    m = vt.utils.transform_matrix(rotation=(0, 0, -100), scale=(1.2, 0.8, 1.0), translation=(1.5, -2.25, 0.0), rotation_order='sxyz', center=c)
+    cases['rot_scale_dh'] = (m, True)
+    m = vt.utils.transform_matrix(rotation=(0, 0, 200), rotation_order='sxyz', center=c); m[2, 3] = float(shape[2] - 4 - (shape[2] % 4))
+    cases['rot200_w_far'] = (m, True)
+    sv = vt.StaticVolume(vol, interpolation=interp, device='gpu:0')
+    base = sv.info().resident_bytes
+    for name, (m, takes) in cases.items():
+        m64 = np.asarray(m, np.float64)
+        assert m64[2, 0] == 0 and m64[2, 1] == 0 and m64[2, 2] == 1 and m64[0, 2] == 0 and m64[1, 2] == 0, name
+        want = oracle.affine(vol, m, interp)
+        got = sv.affine(m, _flags=_native.FORCE_TILED)
+        k = sv.info().last_kernel
+        assert (k == 7) == takes, (interp, shape, name, k)
+        assert np.abs(got - want).max() <= TOL[interp], (interp, shape, name, k)
+        direct = sv.affine(m, _flags=_native.FORCE_DIRECT)
+        if takes:
+            assert np.array_equal(got, direct), (interp, shape, name, float(np.abs(got - direct).max()))
+            other = sv.affine(m, _flags=_native.FORCE_TILED | _native.NO_ROWS)
+            assert sv.info().last_kernel != 7
+            assert np.abs(other - want).max() <= TOL[interp]
+            init = rand_vol(shape, 52)
+            kept = init.copy()
+            sv.affine(m, output=kept, keep_outside=True, _flags=_native.FORCE_TILED)
+            assert sv.info().last_kernel == 7
+            outside = (got == 0) & (direct == 0) & (np.abs(want) == 0)
+            kd = init.copy()
+            sv.affine(m, output=kd, keep_outside=True, _flags=_native.FORCE_DIRECT)
+            assert np.array_equal(kept, kd), (interp, shape, name)
+    if interp != 'linear':
+        assert sv.info().resident_bytes >= base + vol.nbytes          # the x-convolved copy
+        assert sv.release_copies() > 0 and sv.info().resident_bytes == base
+        assert np.array_equal(sv.affine(rot, _flags=_native.FORCE_TILED), sv.affine(rot, _flags=_native.FORCE_DIRECT))
     sv.close()

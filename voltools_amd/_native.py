@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get('VT_LIB') or os.path.join(_HERE, 'lib', 'libvoltools_h
 INTERP_CODES = {'linear': 0, 'bspline': 1, 'bspline_simple': 2, 'filt_bspline': 3, 'filt_bspline_simple': 4}
 
 # enum vt_flags
-OUT_DEVICE, KEEP_OUTSIDE, FORCE_DIRECT, FORCE_TILED, NO_ZSEP, NO_MARCH, NO_ZPAIR, NO_PACKED, FORCE_PACKED, FORCE_XSWAP, NO_RSWAP, NO_QUAD, ONESHOT_EDGE_SCIPY, NO_BLOCK, NO_ZFIR, NO_REORIENT = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768
+OUT_DEVICE, KEEP_OUTSIDE, FORCE_DIRECT, FORCE_TILED, NO_ZSEP, NO_MARCH, NO_ZPAIR, NO_PACKED, FORCE_PACKED, FORCE_XSWAP, NO_RSWAP, NO_QUAD, ONESHOT_EDGE_SCIPY, NO_BLOCK, NO_ZFIR, NO_REORIENT, NO_ROWS = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536
 # enum vt_create_flags
 SRC_DEVICE, SLAB_LO_INTERIOR, SLAB_HI_INTERIOR, SRC_DEFERRED, EDGE_SCIPY = 1, 2, 4, 8, 16
 

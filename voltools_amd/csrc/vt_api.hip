@@ -265,6 +265,7 @@ int init_device(int dev)
             g_init_err[dev] = init_affine_kernels();
             if (g_init_err[dev] == hipSuccess) g_init_err[dev] = init_quad_kernels();
             if (g_init_err[dev] == hipSuccess) g_init_err[dev] = init_block_kernels();
+            if (g_init_err[dev] == hipSuccess) g_init_err[dev] = init_rows_kernels();
             hipDeviceProp_t prop;
             if (g_init_err[dev] == hipSuccess) g_init_err[dev] = hipGetDeviceProperties(&prop, dev);
             if (g_init_err[dev] == hipSuccess) {
@@ -598,6 +599,39 @@ int try_general_reorient(vt_volume* v, const double m[12], int flags, size_t n_o
     return 0;
 }
 
+// Maps that leave axis 2 alone with an integer offset (rotations about axis 2 through the default centre): the row kernel on the plain
+// copy (trilinear) or on its x-convolved form (cubic; built lazily, one relayout pass).  vt_kernels_rows.hip.
+int try_rows(vt_volume* v, const double m[12], int flags, AffineParams* p, TilePlan* plan, Orientation* ori)
+{
+    AffineParams ps;
+    std::memset(&ps, 0, sizeof(ps));
+    TilePlan plans = TilePlan();
+    plans.kind = 0;
+    if (!plan_rows(v, m, flags, &ps, &plans) || plans.kind != 7) return 0;
+    if (is_cubic(v->interp) && !v->d_src_xe) {
+        if (v->xe_retry_in > 0) { --v->xe_retry_in; return 0; }
+        const size_t bytes = (size_t)v->D * v->H * v->P * sizeof(float);
+        if (hipMalloc(reinterpret_cast<void**>(&v->d_src_xe), bytes) != hipSuccess) {
+            (void)hipGetLastError();          // no room for the copy: the exchange path or the general kernels serve this matrix
+            v->d_src_xe = nullptr;
+            v->xe_retry_in = 64;
+            return 0;
+        }
+        const bool simple = v->interp == VT_BSPLINE_SIMPLE || v->interp == VT_FILT_BSPLINE_SIMPLE;
+        if (launch_relayout_xfir(v->d_src, v->d_src_xe, v->D, v->H, v->W, v->P, simple, v->stream) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(v->stream);
+            (void)hipFree(v->d_src_xe);
+            v->d_src_xe = nullptr;
+            v->xe_retry_in = 64;
+            return 0;
+        }
+    }
+    *p = ps; *plan = plans;
+    ori->src_plain = is_cubic(v->interp) ? v->d_src_xe : v->d_src;
+    return 0;
+}
+
 void note_launch(vt_volume* v, int kind, const TilePlan& plan, const AffineParams& p, size_t n_out)
 {
     v->last_kernel = kind;
@@ -708,6 +742,8 @@ int launch_planned(vt_volume* v, const TilePlan& plan, const AffineParams& p, co
     } else if (plan.kind == 4) {
         VT_HIP(launch_affine_march(plan.cfg, v->interp, ori.src_plain, d_out, p, plan.grid, plan.lds_bytes, v->stream));
 #endif
+    } else if (plan.kind == 7) {
+        VT_HIP(launch_affine_rows(v->interp, ori.src_plain, d_out, v->d_zeros, p, plan.lds_bytes, v->stream));
     } else if (plan.kind >= 2) {
         VT_HIP(launch_affine_tiled(plan.cfg, v->interp, plan.kind == 3, ori.src_plain, d_out, v->d_zeros, p, plan.grid, plan.lds_bytes, v->stream));
     } else {
@@ -761,7 +797,8 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
         ori.srcD = v->D; ori.srcH = v->H; ori.rowW = v->W; ori.rowP = v->P;
         const int pf = flags | deny;
         // single-axis rotations about axes 1 / 2 and in-plane maps near a quarter turn march on an exchanged resident copy
-        if ((rc = try_axis1_exchange(v, m, pf, n_out, &p, &plan, &ori))) return rc;
+        if ((rc = try_rows(v, m, pf, &p, &plan, &ori))) return rc;
+        if (plan.kind == 0 && (rc = try_axis1_exchange(v, m, pf, n_out, &p, &plan, &ori))) return rc;
         if (plan.kind == 0 && (rc = try_axis2_exchange(v, m, pf, n_out, &p, &plan, &ori))) return rc;
         if (plan.kind == 0 && (rc = try_inplane_transposed(v, m, pf, n_out, &p, &plan, &ori))) return rc;
         if (plan.kind == 0 && (rc = try_general_reorient(v, m, pf, n_out, &p, &plan, &ori))) return rc;
@@ -1518,6 +1555,7 @@ int vt_volume_destroy(vt_volume_t* v)
     if (v->d_src_r_q) hipFree(v->d_src_r_q);
     if (v->d_src_x_q) hipFree(v->d_src_x_q);
     for (int i = 0; i < 4; ++i) if (v->d_src_qe[i]) hipFree(v->d_src_qe[i]);
+    if (v->d_src_xe) hipFree(v->d_src_xe);
     if (v->d_tmp_x) hipFree(v->d_tmp_x);
     if (v->d_scratch_out) cached_free(v->dev, v->d_scratch_out, v->scratch_elems * sizeof(float));
     if (v->d_proj_tmp) hipFree(v->d_proj_tmp);
@@ -1541,7 +1579,7 @@ int vt_volume_release_copies(vt_volume_t* v, uint64_t* freed_bytes)
     if ((rc = vt_volume_info(v, &before))) return rc;
     VT_HIP(hipStreamSynchronize(v->stream));      // no launch may still be reading what is freed
     float** const slots[] = {&v->d_src_t, &v->d_src_x, &v->d_src_r, &v->d_src_q, &v->d_src_t_q, &v->d_src_r_q, &v->d_src_x_q,
-                             &v->d_src_qe[0], &v->d_src_qe[1], &v->d_src_qe[2], &v->d_src_qe[3], &v->d_tmp_x,
+                             &v->d_src_qe[0], &v->d_src_qe[1], &v->d_src_qe[2], &v->d_src_qe[3], &v->d_tmp_x, &v->d_src_xe,
 #ifdef VT_LEGACY
                              &v->d_src_zp, &v->d_src_t_zp, &v->d_src_r_zp, &v->d_src_x_zp,
 #endif
@@ -1551,6 +1589,7 @@ int vt_volume_release_copies(vt_volume_t* v, uint64_t* freed_bytes)
     v->tmp_x_elems = 0;
     for (int i = 0; i < 4; ++i) { v->quad_bytes[i] = 0; v->quade_bytes[i] = 0; }
     for (int i = 0; i < 8; ++i) v->copy_retry_in[i] = 0;      // memory was just returned: a copy that did not fit may fit now
+    v->xe_retry_in = 0;
     if ((rc = vt_volume_info(v, &after))) return rc;
     if (freed_bytes) *freed_bytes = before.resident_bytes - after.resident_bytes;
     return 0;
@@ -1577,7 +1616,7 @@ int vt_volume_info(const vt_volume_t* v, vt_volume_info_t* info)
     info->last_lds_bytes = v->last_lds_bytes; info->last_grid = v->last_grid;
     info->prefilter_ms = v->prefilter_ms;
     const uint64_t plain = (uint64_t)v->D * v->H * v->P * sizeof(float);
-    info->resident_bytes = plain + (v->d_src_t ? plain : 0) +
+    info->resident_bytes = plain + (v->d_src_t ? plain : 0) + (v->d_src_xe ? plain : 0) +
                            (v->proj ? (uint64_t)3 * v->proj->H * v->proj->P * sizeof(float) : 0) +
                            (v->d_src_r ? (uint64_t)v->D * v->W * v->Pr * sizeof(float) : 0) +
                            (v->d_src_x ? (uint64_t)v->W * v->H * v->Px * sizeof(float) : 0) +

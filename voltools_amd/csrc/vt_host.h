@@ -31,6 +31,7 @@ struct Tuning {
     int quad_pingpong = 1;         // VT_QUAD_PINGPONG: 1 = every other launch of a handle walks the chunk layers from the last to the first; 0 / 2 = never / always
     int quad_zid = 1;              // VT_QUAD_ZID=0: trilinear launches with fz == 0 keep the two-plane kernel (round-3 A/B)
 int reorient = 4;              // VT_REORIENT: general matrices sample the resident copy whose rows follow the output's w axis, built at the n-th request (0 = never)
+    int rows = 1;                  // VT_ROWS=0: maps that leave axis 2 alone take the axis-exchange path instead of the row kernel (kind 7)
         int quad_zfir = 1;             // VT_QUAD_ZFIR=0: cubic launches with fz == 0 keep the four-plane kernel (round-4 A/B: the z-convolved copy)
     int zid_dch = 0;               // VT_ZID_DCH: chunk depth of the integer-offset trilinear kernel (0 = the trilinear default)
     int quad_nt = -1;              // VT_QUAD_NT: 1 / 0 = nontemporal / plain output stores of the plane-quad kernel, -1 = planner's choice
@@ -71,6 +72,7 @@ int reorient = 4;              // VT_REORIENT: general matrices sample the resid
 #endif
         quad_pingpong = num("VT_QUAD_PINGPONG", 1);
         quad_zfir = num("VT_QUAD_ZFIR", 1);
+        rows = num("VT_ROWS", 1);
         reorient = num("VT_REORIENT", 4);
         no_proj_cache = std::getenv("VT_NO_PROJ_CACHE") != nullptr;
         zid_dch = num("VT_ZID_DCH", 0);
@@ -112,9 +114,11 @@ struct vt_volume {
     float* d_src_r_q = nullptr;
     float* d_src_x_q = nullptr;
     size_t quad_bytes[4] = {0, 0, 0, 0};   // allocation sizes of the four quad copies (vt_volume_info)
+    float* d_src_xe = nullptr;         // plain-layout copy convolved along axis 2 with the cubic weights of fraction 0 (row kernel, kind 7, cubic; vt_kernels_rows.hip: relayout_xfir); lazy
     float* d_src_qe[4] = {nullptr, nullptr, nullptr, nullptr};   // plane-quad copies of the Z-CONVOLVED volume per orientation (cubic launches with an integer axis-0 offset; vt_kernels_quad.hip: relayout_zquad_fir); lazy
     size_t quade_bytes[4] = {0, 0, 0, 0};
     int reorient_asked[3] = {0, 0, 0};   // general matrices that asked for the copy whose fastest axis is source axis 0 / 1 (vt_api.hip: try_general_reorient)
+    int xe_retry_in = 0;               // calls to go before the x-convolved copy is attempted again after an allocation failure
     int copy_retry_in[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // calls to go before a quad copy that could not be allocated is attempted again (per orientation; 4..7: the z-convolved ones)
 #ifdef VT_LEGACY
     // plane-pair copies of the four orientations (round 1's cubic marching kernel, kind 5): test build only
@@ -166,5 +170,6 @@ inline int resident_pitch(int W) { return (W + 4 + 31) & ~31; }
 // The launch planner (vt_plan.hip): kernel family, tile shape, LDS budget and grid for one matrix on one handle.  Fills every
 // field of `p` the chosen kernel reads; plan->kind = 1 (direct gather) when nothing tiled fits.  Host side, ~10 us.
 void plan_launch(const vt_volume* v, const double m[12], int flags, AffineParams* p, TilePlan* plan);
+bool plan_rows(const vt_volume* v, const double m[12], int flags, AffineParams* p, TilePlan* plan);
 
 }  // namespace vt

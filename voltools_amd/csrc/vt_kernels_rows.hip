@@ -1,0 +1,230 @@
+// vt_kernels_rows.hip -- kind 7: maps that leave axis 2 alone, src_w = w + t with an integer t that is a multiple of four
+// ([a b 0 t0; c e 0 t1; 0 0 1 t]: every rotation about axis 2 through the default centre, scaled / sheared or not in the (d, h) plane).
+//
+// The resident plain layout [z][y][x] is, for these maps, what the plane-quad copy is for rotations about axis 0: the axis the map
+// leaves alone is the CONTIGUOUS one.  A wave owns one output pixel (d, h) and 64 consecutive w: the in-plane stencil -- 2 x 2 or
+// 4 x 4 source rows (z, y) -- and its weights are the same for all 64 lanes, every tap is one conflict-free `ds_read_b32` of 64
+// consecutive floats of a staged source row, and the 64 results leave as one 256-byte store.  No exchanged copy, no exchanged
+// result, no transpose pass (the marching kernels need all three for these maps: 0.21 + 0.19 ms at 512^3; writing the caller's
+// array from a kernel that marches along w was measured in four forms and never beat that, profiles/r04_axis2_direct_output.txt).
+//
+// Arithmetic, operation for operation that of `affine_direct` / the oracle (transforms.py:253-281, helper_interpolation.h:3-68):
+//   * coordinates of rows 0 and 1 through canonical_coord (their w term is fma(0, w, .) exactly), floor and float32 fraction;
+//   * trilinear: the x-lerp of a row pair is fmaf(0, b - a, a) == a for finite data (the fraction along w is exactly 0), so one
+//     tap per row; then the y- and z-lerps in the usual order;
+//   * cubic: the x-sum of a row, w0 c[x-1] + w1 c[x] + w2 c[x+1] (+ 0 c[x+2]) with the weights of fraction 0, is formed ONCE, when the
+//     x-convolved copy is built (relayout_xfir: the same three operations in the same order), and the kernel reads it as one tap;
+//     then accy and the z sum as in direct_sample.  Bit-identical to affine_direct on finite data.
+// A non-finite sample in the tap column of weight exactly 0 does not reach the output (as for KIND 3 / KIND 4).
+#include "vt_internal.h"
+#include "vt_device.h"
+
+namespace vt {
+
+constexpr int kRowPD = 4, kRowPH = 8, kRowRun = 64;      // pixels of a workgroup's tile (d x h: one wave per d, eight h each), w per wave
+
+// dst[z][y][x] = fmaf(w2, c[x+1], fmaf(w1, c[x], w0 * c[x-1])), zero border, pad columns zero
+__global__ __launch_bounds__(256) void relayout_xfir(const float* __restrict__ src, float* __restrict__ dst, int64_t rows, int W, int P, int simple)
+{
+    float w[4];
+    if (simple) cubic_weights<true>(0.0f, w); else cubic_weights<false>(0.0f, w);
+    const int64_t row = (int64_t)blockIdx.y;
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows || x >= P) return;
+    const float* s = src + row * P;
+    float val = 0.0f;
+    if (x < W) {
+        const float cm = x > 0 ? s[x - 1] : 0.0f, c0 = s[x], cp = x + 1 < W ? s[x + 1] : 0.0f;
+        val = fmaf(w[2], cp, fmaf(w[1], c0, w[0] * cm));
+    }
+    dst[row * P + x] = val;
+}
+
+hipError_t launch_relayout_xfir(const float* src, float* dst, int D, int H, int W, int P, bool simple, hipStream_t stream)
+{
+    const int64_t rows = (int64_t)D * H;
+    if (rows > 0x7fffffffLL / 1 || rows > 65535LL * 65535LL) return hipErrorInvalidValue;
+    // grid.y <= 65535: rows folded into y * z would need a second index; the planner refuses D * H > 2^31 anyway and splits here
+    const int64_t per = 65535;
+    for (int64_t r0 = 0; r0 < rows; r0 += per) {
+        const int64_t n = std::min<int64_t>(per, rows - r0);
+        hipLaunchKernelGGL(relayout_xfir, dim3((unsigned)((P + 255) / 256), (unsigned)n), dim3(256), 0, stream, src + r0 * P, dst + r0 * P, n, W, P,
+                           simple ? 1 : 0);
+    }
+    return hipGetLastError();
+}
+
+// KIND 0: trilinear (2 x 2 rows of the plain copy), KIND 1: cubic (4 x 4 rows of the x-convolved copy; flag bit 18: `_simple` weights)
+template <int KIND>
+__global__ __launch_bounds__(256) void affine_rows(const float* __restrict__ src, float* __restrict__ out, const float* __restrict__ zeros16,
+                                                   const AffineParams p)
+{
+    constexpr int HALO = KIND == 0 ? 0 : 1, NT = KIND == 0 ? 2 : 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int run = blockIdx.x, th_i = blockIdx.y, td_i = blockIdx.z;
+    const int d0 = td_i * kRowPD, h0 = th_i * kRowPH, w0 = run * kRowRun;
+    const int Ly = p.Ly, Lz = p.Lz;
+    const bool keep = (p.flags & VT_KEEP_OUTSIDE) != 0;
+
+    // (z, y) box of the tile's taps: rows 0 and 1 of the matrix ignore w
+    double base[2], lo[2], hi[2];
+    bool any_valid = true;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        base[r] = fma(p.m[4 * r], (double)d0, fma(p.m[4 * r + 1], (double)h0, p.m[4 * r + 3]));
+        lo[r] = base[r] + p.neg[r];
+        hi[r] = base[r] + p.pos[r];
+        any_valid = any_valid && (hi[r] >= p.vlo[r] - kTileMargin) && (lo[r] < p.vhi[r] + kTileMargin);
+    }
+    const int t2 = p.zoff;                        // src_w = w + t2 (the planner's integer multiple of four)
+    any_valid = any_valid && ((double)(w0 + kRowRun - 1 + t2) >= p.vlo[2] - kTileMargin) && ((double)(w0 + t2) < p.vhi[2] + kTileMargin);
+    const int w = w0 + lane;
+    if (!any_valid) {
+        if (!keep && w < p.oW) {
+            const int d = d0 + wv;
+            if (d < p.oD)
+                for (int i = 0; i < kRowPH && h0 + i < p.oH; ++i) out[((int64_t)d * p.oH + (h0 + i)) * p.oW + w] = 0.0f;
+        }
+        return;
+    }
+    int oz, oy;
+    {
+        const int f0 = (int)floor(lo[0]), f1 = (int)floor(lo[1]);
+        // (the builtin, not an inline-asm v_readfirstlane: the compiler's hazard recogniser does not look into asm statements -- no wait
+        //  state between the v_cvt_i32_f64 that produces the value and the lane read of it --, and the cubic instantiation got a stale
+        //  origin in some waves: rows staged by different waves then disagreed and results changed from launch to launch)
+        oz = __builtin_amdgcn_readfirstlane(f0) - HALO;
+        oy = __builtin_amdgcn_readfirstlane(f1) - HALO;
+    }
+
+    // ---- stage Lz x Ly source rows, 64 floats each (16 vectors of 16 bytes): vector v lands at lds + 16 v ----
+    {
+        const int total = Lz * Ly * 16;
+        const int x0 = w0 + t2;                   // multiple of 4: whole vectors are inside or outside the row
+        const int wave_first = __builtin_amdgcn_readfirstlane(tid & ~63);
+        for (int vb = wave_first; vb < total; vb += 256) {
+            const int v = vb + lane;
+            const int row = v >> 4, seg = v & 15;
+            const int zz = (int)__umulhi((unsigned)row, p.psv_magic);        // row / Ly (host constant: floor(2^32 / Ly) + 1)
+            const int yy = row - zz * Ly;
+            const int gz = oz + zz, gy = oy + yy, gx = x0 + 4 * seg;
+            const bool inb = (unsigned)gz < (unsigned)p.sD && (unsigned)gy < (unsigned)p.sH && (unsigned)gx < (unsigned)p.sP;
+            const float* g = inb ? src + (((int64_t)gz * p.sH + gy) * p.sP + gx) : zeros16;
+            if (v < total)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                 (__attribute__((address_space(3))) void*)(lds + 4 * vb), 16, 0, 0);
+        }
+    }
+
+    // ---- one wave per d, eight pixels (h) each ----
+    // Everything about a pixel but its 64 samples is the same for the wave's 64 lanes: lane i < 8 works out pixel i (coordinates in
+    // float64, fractions, the eight weights, the first tap row) while the staged rows are still in flight -- as vector work per pixel
+    // the same arithmetic was ~150 instructions for 64 voxels, three times the taps and sums ([measured] 512^3 cubic 0.66 ms in that form) --
+    const int d = d0 + wv;
+    const int hl = h0 + (lane & 7);
+    const double s0 = canonical_coord(p, 0, d, hl, 0), s1 = canonical_coord(p, 1, d, hl, 0);      // the w column of rows 0 / 1 is exactly 0
+    const double fzd = floor(s0), fyd = floor(s1);
+    const float fz = (float)(s0 - fzd), fy = (float)(s1 - fyd);
+    float wy[4] = {0.f, 0.f, 0.f, 0.f}, wz[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (KIND != 0) {
+        if (p.flags & (1 << 18)) { cubic_weights<true>(fy, wy); cubic_weights<true>(fz, wz); }
+        else { cubic_weights<false>(fy, wy); cubic_weights<false>(fz, wz); }
+    }
+    const int rz_l = (int)fzd - HALO - oz, ry_l = (int)fyd - HALO - oy;
+    // (the box is sized from the tile's corners with one row of slack; a pixel whose own chain rounds across an integer the corners'
+    //  did not could still miss it by a row: such a pixel reads its taps from global memory -- never seen)
+    const int in_box_l = (rz_l >= 0 && ry_l >= 0 && rz_l + NT <= Lz && ry_l + NT <= Ly) ? 1 : 0;
+    const int in_zy_l = ((s0 >= p.vlo[0]) && (s0 < p.vhi[0]) && (s1 >= p.vlo[1]) && (s1 < p.vhi[1]) && hl < p.oH && d < p.oD) ? 1 : 0;
+    // ... and leaves them in LDS, 16 dwords per pixel behind the staged rows (every lane of the wave reads them back from one address: a
+    // broadcast).  (Taking them across lanes with v_readlane instead gave results that changed from launch to launch.)
+    float* const prm = lds + Lz * Ly * kRowRun + (wv * kRowPH) * 16;
+    if (lane < kRowPH) {
+        float* q = prm + lane * 16;
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<v4f*>(q) = v4f{wy[0], wy[1], wy[2], wy[3]};
+        *reinterpret_cast<v4f*>(q + 4) = v4f{wz[0], wz[1], wz[2], wz[3]};
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        // (integers travel as integers: a small integer's bit pattern is a subnormal float, and float moves may flush it)
+        *reinterpret_cast<v4f*>(q + 8) = v4f{fy, fz, 0.f, 0.f};
+        *reinterpret_cast<v4i*>(q + 12) = v4i{rz_l * Ly + ry_l, in_zy_l | (in_box_l << 1), rz_l, ry_l};
+    }
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    if (d >= p.oD) return;
+    const double sw = (double)w + p.m[11];        // == fma(0, d, fma(0, h, fma(1, w, t))) of the canonical chain
+    const bool in_x = (sw >= p.vlo[2]) && (sw < p.vhi[2]);
+    const unsigned lds_b = lds_byte_address(lds) + 4u * (unsigned)lane;
+    float* optr = out + ((int64_t)d * p.oH + h0) * p.oW + w;
+#pragma unroll
+    for (int i = 0; i < kRowPH; ++i) {
+        if (h0 + i >= p.oH) break;
+        // every branch up to the store is uniform over the wave: the samples of all 64 lanes are formed (columns outside the volume were
+        // staged as zeros), the store alone looks at the lane's own w
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f pwy = *reinterpret_cast<const v4f*>(prm + i * 16), pwz = *reinterpret_cast<const v4f*>(prm + i * 16 + 4);
+        const v4f pf = *reinterpret_cast<const v4f*>(prm + i * 16 + 8);
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        const v4i pi = *reinterpret_cast<const v4i*>(prm + i * 16 + 12);
+        const int fl = __builtin_amdgcn_readfirstlane(pi[1]);
+        const bool inside_zy = (fl & 1) != 0;
+        float val = 0.f;
+        if (inside_zy) {
+            const bool in_box = (fl & 2) != 0;
+            const unsigned a0 = lds_b + 256u * (unsigned)__builtin_amdgcn_readfirstlane(pi[0]);
+            float t[NT][NT];
+            if (in_box) {
+#pragma unroll
+                for (int c = 0; c < NT; ++c)
+#pragma unroll
+                    for (int b = 0; b < NT; ++b)
+                        t[c][b] = *reinterpret_cast<const __attribute__((address_space(3))) float*>((size_t)(a0 + 256u * (unsigned)(c * Ly + b)));
+            } else {
+                const int gz = oz + __builtin_amdgcn_readfirstlane(pi[2]);
+                const int gy = oy + __builtin_amdgcn_readfirstlane(pi[3]);
+#pragma unroll
+                for (int c = 0; c < NT; ++c)
+#pragma unroll
+                    for (int b = 0; b < NT; ++b) t[c][b] = fetch0(src, p, gz + c, gy + b, w + t2);
+            }
+            if constexpr (KIND == 0) {
+                const float y0 = fmaf(pf[0], t[0][1] - t[0][0], t[0][0]);
+                const float y1 = fmaf(pf[0], t[1][1] - t[1][0], t[1][0]);
+                val = fmaf(pf[1], y1 - y0, y0);
+            } else {
+#pragma unroll
+                for (int c = 0; c < NT; ++c) {
+                    float accy = 0.f;
+#pragma unroll
+                    for (int b = 0; b < NT; ++b) accy = fmaf(pwy[b], t[c][b], accy);
+                    val = fmaf(pwz[c], accy, val);
+                }
+            }
+        }
+        if (w < p.oW) {
+            if (inside_zy && in_x) optr[(int64_t)i * p.oW] = val;
+            else if (!keep) optr[(int64_t)i * p.oW] = 0.0f;
+        }
+    }
+}
+
+hipError_t init_rows_kernels()
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(affine_rows<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(affine_rows<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+void rows_tile(int* pd, int* ph, int* run) { *pd = kRowPD; *ph = kRowPH; *run = kRowRun; }
+
+hipError_t launch_affine_rows(int interp, const float* src, float* out, const float* zeros16, const AffineParams& p, int lds_bytes, hipStream_t stream)
+{
+    const dim3 g((unsigned)((p.oW + kRowRun - 1) / kRowRun), (unsigned)((p.oH + kRowPH - 1) / kRowPH), (unsigned)((p.oD + kRowPD - 1) / kRowPD));
+    if (interp_kind(interp) == 0) hipLaunchKernelGGL(affine_rows<0>, g, dim3(256), lds_bytes, stream, src, out, zeros16, p);
+    else hipLaunchKernelGGL(affine_rows<1>, g, dim3(256), lds_bytes, stream, src, out, zeros16, p);
+    return hipGetLastError();
+}
+
+}  // namespace vt

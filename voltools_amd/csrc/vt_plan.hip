@@ -1023,9 +1023,9 @@ const Family kFamilies[] = {
 
 }  // namespace
 
-void plan_launch(const vt_volume* v, const double m[12], int flags, AffineParams* p, TilePlan* plan)
+// the fields every family reads: matrix, dims, output strides, the skirt rule's valid intervals
+static void plan_prepare(const vt_volume* v, const double m[12], int flags, AffineParams* p, TilePlan* plan)
 {
-    const int64_t n_out = (int64_t)v->oD * v->oH * v->oW;
     std::memcpy(p->m, m, sizeof(double) * 12);
     p->sD = v->D; p->sH = v->H; p->sW = v->W; p->sP = v->P;
     for (int r = 0; r < 3; ++r) {
@@ -1059,6 +1059,58 @@ void plan_launch(const vt_volume* v, const double m[12], int flags, AffineParams
     p->zero_off = ((v->W + 3) & ~3) * 4;
 
     plan->kind = 1; plan->cfg = -1; plan->td = plan->th = plan->tw = 0; plan->lds_bytes = 0; plan->grid = 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// rows: maps that leave axis 2 alone (kind 7, vt_kernels_rows.hip).  Planned by do_affine ahead of the axis exchanges, on the handle's
+// own orientation only; false = not this class / does not fit, the plan is untouched (kind 0) and the usual dispatch follows.
+// ---------------------------------------------------------------------------------------------------
+bool plan_rows(const vt_volume* v, const double m[12], int flags, AffineParams* p, TilePlan* plan)
+{
+    const int64_t n_out = (int64_t)v->oD * v->oH * v->oW;
+    if (flags & (VT_FORCE_DIRECT | VT_NO_ZSEP | VT_NO_MARCH | VT_FORCE_XSWAP | VT_FORCE_PACKED | VT_NO_ROWS)) return false;
+    if (v->tune.rows == 0) return false;
+    if (n_out < 64 * 64 * 64 && !(flags & VT_FORCE_TILED)) return false;
+    // [a b 0 t0; c e 0 t1; 0 0 1 t], t an integer multiple of four (16-byte staging vectors); not also axis-0-separable (that class
+    // has the plane-quad kernel: pure translations, the identity)
+    if (!(m[2] == 0.0 && m[6] == 0.0 && m[8] == 0.0 && m[9] == 0.0 && m[10] == 1.0)) return false;
+    if (m[0] == 1.0 && m[1] == 0.0 && m[4] == 0.0) return false;
+    const double t = m[11];
+    if (!(std::fabs(t) < 1.0e9) || t != std::floor(t) || ((int64_t)t & 3) != 0) return false;
+    for (int i = 0; i < 12; ++i) if (!(std::fabs(m[i]) < 1.0e9)) return false;
+    int pd, ph, run;
+    rows_tile(&pd, &ph, &run);
+    if ((v->oD + pd - 1) / pd > 65535 || (v->oH + ph - 1) / ph > 65535) return false;
+    const bool cubic = is_cubic(v->interp);
+    const int halo2 = cubic ? 2 : 0;
+    int L[2];
+    for (int r = 0; r < 2; ++r) {
+        const double ext = std::fabs(m[4 * r]) * (pd - 1) + std::fabs(m[4 * r + 1]) * (ph - 1);
+        if (!(ext < 200.0)) return false;
+        L[r] = (int)std::floor(ext) + 3 + halo2;          // floor(hi) - floor(lo) <= floor(ext) + 1, + 1 upper tap, + 1 slack
+    }
+    const int lds = L[0] * L[1] * run * 4 + 4 * ph * 16 * 4;       // the staged rows + 16 dwords per pixel (four waves x eight pixels)
+    if (lds > 64 * 1024 || lds > v->lds_limit) return false;      // (strong minification in the (d, h) plane: the general kernels serve it)
+    plan_prepare(v, m, flags, p, plan);
+    const int T[3] = {pd, ph, 1};
+    set_tile_reach(p, m, T, 0);
+    p->Lz = L[0]; p->Ly = L[1]; p->Lx = run; p->Lx_used = run;
+    p->psv_magic = (uint32_t)(4294967296.0 / (double)L[1]) + 1u;
+    p->zoff = (int32_t)t;
+    p->fz = 0.0f;
+    p->flags = (flags & VT_KEEP_OUTSIDE);
+    if (v->interp == VT_BSPLINE_SIMPLE || v->interp == VT_FILT_BSPLINE_SIMPLE) p->flags |= (1 << 18);
+    plan->kind = 7; plan->cfg = 0; plan->td = pd; plan->th = ph; plan->tw = run;
+    plan->lds_bytes = lds;
+    plan->grid = (int)std::min<int64_t>(0x7fffffff, (int64_t)((v->oW + run - 1) / run) * ((v->oH + ph - 1) / ph) * ((v->oD + pd - 1) / pd));
+    plan->blocks_per_cu = std::max(1, std::min(8, (160 * 1024) / std::max(1, lds)));
+    return true;
+}
+
+void plan_launch(const vt_volume* v, const double m[12], int flags, AffineParams* p, TilePlan* plan)
+{
+    const int64_t n_out = (int64_t)v->oD * v->oH * v->oW;
+    plan_prepare(v, m, flags, p, plan);
     bool want_tiled = n_out >= 64 * 64 * 64;
     if (flags & VT_FORCE_TILED) want_tiled = true;
     if (flags & VT_FORCE_DIRECT) want_tiled = false;
