@@ -6,6 +6,7 @@
 // of the experiments are gathered in vt_volume::tune (vt_host.h).
 //
 //   family   kind  kernel (file)                                   serves
+//   rows       7   affine_rows         (vt_kernels_rows.hip)       maps that leave axis 2 alone, integer offset (plan_rows: planned by do_affine ahead of the rest)
 //   quad       8   affine_march4       (vt_kernels_quad.hip)       axis-0-separable matrices, every interpolation
 //   block      9   affine_block        (vt_kernels_block.hip)      general matrices, cubic, outputs >= 256^3
 //   box        2   affine_tiled        (vt_kernels_affine.hip)     any matrix whose tile footprint's bounding box fits LDS
