@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void relayout_xfir(const float* __restrict__ s
 {
     float w[4];
     if (simple) cubic_weights<true>(0.0f, w); else cubic_weights<false>(0.0f, w);
-    const int64_t row = (int64_t)blockIdx.y;
+    const int64_t row = (int64_t)blockIdx.y + (int64_t)gridDim.y * blockIdx.z;
     const int x = blockIdx.x * 256 + threadIdx.x;
     if (row >= rows || x >= P) return;
     const float* s = src + row * P;
@@ -43,14 +43,9 @@ __global__ __launch_bounds__(256) void relayout_xfir(const float* __restrict__ s
 hipError_t launch_relayout_xfir(const float* src, float* dst, int D, int H, int W, int P, bool simple, hipStream_t stream)
 {
     const int64_t rows = (int64_t)D * H;
-    if (rows > 0x7fffffffLL / 1 || rows > 65535LL * 65535LL) return hipErrorInvalidValue;
-    // grid.y <= 65535: rows folded into y * z would need a second index; the planner refuses D * H > 2^31 anyway and splits here
-    const int64_t per = 65535;
-    for (int64_t r0 = 0; r0 < rows; r0 += per) {
-        const int64_t n = std::min<int64_t>(per, rows - r0);
-        hipLaunchKernelGGL(relayout_xfir, dim3((unsigned)((P + 255) / 256), (unsigned)n), dim3(256), 0, stream, src + r0 * P, dst + r0 * P, n, W, P,
-                           simple ? 1 : 0);
-    }
+    const unsigned gy = (unsigned)std::min<int64_t>(rows, 65535), gz = (unsigned)((rows + gy - 1) / gy);
+    if (rows <= 0 || gz > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(relayout_xfir, dim3((unsigned)((P + 255) / 256), gy, gz), dim3(256), 0, stream, src, dst, rows, W, P, simple ? 1 : 0);
     return hipGetLastError();
 }
 
