@@ -743,7 +743,7 @@ int launch_planned(vt_volume* v, const TilePlan& plan, const AffineParams& p, co
         VT_HIP(launch_affine_march(plan.cfg, v->interp, ori.src_plain, d_out, p, plan.grid, plan.lds_bytes, v->stream));
 #endif
     } else if (plan.kind == 7) {
-        VT_HIP(launch_affine_rows(v->interp, ori.src_plain, d_out, v->d_zeros, p, plan.lds_bytes, v->stream));
+        VT_HIP(launch_affine_rows(v->interp, plan.td, ori.src_plain, d_out, v->d_zeros, p, plan.lds_bytes, v->stream));
     } else if (plan.kind >= 2) {
         VT_HIP(launch_affine_tiled(plan.cfg, v->interp, plan.kind == 3, ori.src_plain, d_out, v->d_zeros, p, plan.grid, plan.lds_bytes, v->stream));
     } else {

@@ -31,6 +31,7 @@ struct Tuning {
     int quad_pingpong = 1;         // VT_QUAD_PINGPONG: 1 = every other launch of a handle walks the chunk layers from the last to the first; 0 / 2 = never / always
     int quad_zid = 1;              // VT_QUAD_ZID=0: trilinear launches with fz == 0 keep the two-plane kernel (round-3 A/B)
 int reorient = 4;              // VT_REORIENT: general matrices sample the resident copy whose rows follow the output's w axis, built at the n-th request (0 = never)
+    int rows_pd = 8;               // VT_ROWS_PD=4: the row kernel's pixel tile is 4 x 8 (four waves) instead of 8 x 8
     int rows = 1;                  // VT_ROWS=0: maps that leave axis 2 alone take the axis-exchange path instead of the row kernel (kind 7)
         int quad_zfir = 1;             // VT_QUAD_ZFIR=0: cubic launches with fz == 0 keep the four-plane kernel (round-4 A/B: the z-convolved copy)
     int zid_dch = 0;               // VT_ZID_DCH: chunk depth of the integer-offset trilinear kernel (0 = the trilinear default)
@@ -73,6 +74,7 @@ int reorient = 4;              // VT_REORIENT: general matrices sample the resid
         quad_pingpong = num("VT_QUAD_PINGPONG", 1);
         quad_zfir = num("VT_QUAD_ZFIR", 1);
         rows = num("VT_ROWS", 1);
+        rows_pd = num("VT_ROWS_PD", 8);
         reorient = num("VT_REORIENT", 4);
         no_proj_cache = std::getenv("VT_NO_PROJ_CACHE") != nullptr;
         zid_dch = num("VT_ZID_DCH", 0);

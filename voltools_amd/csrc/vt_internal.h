@@ -220,8 +220,8 @@ hipError_t launch_relayout_zquad(const float* src, float* dst, int D, int H, int
 // vt_kernels_rows.hip (kind 7: maps that leave axis 2 alone)
 hipError_t launch_relayout_xfir(const float* src, float* dst, int D, int H, int W, int P, bool simple, hipStream_t stream);
 hipError_t init_rows_kernels();
-void rows_tile(int* pd, int* ph, int* run);
-hipError_t launch_affine_rows(int interp, const float* src, float* out, const float* zeros16, const AffineParams& p, int lds_bytes, hipStream_t stream);
+void rows_tile(int* ph, int* run);
+hipError_t launch_affine_rows(int interp, int pd, const float* src, float* out, const float* zeros16, const AffineParams& p, int lds_bytes, hipStream_t stream);
 hipError_t launch_relayout_zquad_fir(const float* src, float* dst, int D, int H, int W, int P, int Pq, bool simple, hipStream_t stream);
 hipError_t launch_affine_quad(int cfg, int interp, const float* srcq, float* out, const AffineParams& p,
                               int grid, int lds_bytes, hipStream_t stream);

@@ -21,7 +21,7 @@
 
 namespace vt {
 
-constexpr int kRowPD = 4, kRowPH = 8, kRowRun = 64;      // pixels of a workgroup's tile (d x h: one wave per d, eight h each), w per wave
+constexpr int kRowPH = 8, kRowRun = 64;      // a wave's pixels (one d, eight h) and its run of w; a workgroup's tile is PD x 8 pixels, PD waves
 
 // dst[z][y][x] = fmaf(w2, c[x+1], fmaf(w1, c[x], w0 * c[x-1])), zero border, pad columns zero
 __global__ __launch_bounds__(256) void relayout_xfir(const float* __restrict__ src, float* __restrict__ dst, int64_t rows, int W, int P, int simple)
@@ -50,14 +50,15 @@ hipError_t launch_relayout_xfir(const float* src, float* dst, int D, int H, int 
 }
 
 // KIND 0: trilinear (2 x 2 rows of the plain copy), KIND 1: cubic (4 x 4 rows of the x-convolved copy; flag bit 18: `_simple` weights)
-template <int KIND>
-__global__ __launch_bounds__(256) void affine_rows(const float* __restrict__ src, float* __restrict__ out, const float* __restrict__ zeros16,
+template <int KIND, int PD>
+__global__ __launch_bounds__(64 * PD) void affine_rows(const float* __restrict__ src, float* __restrict__ out, const float* __restrict__ zeros16,
                                                    const AffineParams p)
 {
     constexpr int HALO = KIND == 0 ? 0 : 1, NT = KIND == 0 ? 2 : 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int run = blockIdx.x, th_i = blockIdx.y, td_i = blockIdx.z;
+    constexpr int kRowPD = PD, NTHR = 64 * PD;
     const int d0 = td_i * kRowPD, h0 = th_i * kRowPH, w0 = run * kRowRun;
     const int Ly = p.Ly, Lz = p.Lz;
     const bool keep = (p.flags & VT_KEEP_OUTSIDE) != 0;
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void affine_rows(const float* __restrict__ src
         const int total = Lz * Ly * 16;
         const int x0 = w0 + t2;                   // multiple of 4: whole vectors are inside or outside the row
         const int wave_first = __builtin_amdgcn_readfirstlane(tid & ~63);
-        for (int vb = wave_first; vb < total; vb += 256) {
+        for (int vb = wave_first; vb < total; vb += NTHR) {
             const int v = vb + lane;
             const int row = v >> 4, seg = v & 15;
             const int zz = (int)__umulhi((unsigned)row, p.psv_magic);        // row / Ly (host constant: floor(2^32 / Ly) + 1)
@@ -205,20 +206,29 @@ __global__ __launch_bounds__(256) void affine_rows(const float* __restrict__ src
     }
 }
 
-hipError_t init_rows_kernels()
+typedef void (*rows_fn)(const float*, float*, const float*, const AffineParams);
+static rows_fn rows_entry(int kind, int pd)
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(affine_rows<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(affine_rows<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (pd == 8) return kind == 0 ? affine_rows<0, 8> : affine_rows<1, 8>;
+    return kind == 0 ? affine_rows<0, 4> : affine_rows<1, 4>;
 }
 
-void rows_tile(int* pd, int* ph, int* run) { *pd = kRowPD; *ph = kRowPH; *run = kRowRun; }
-
-hipError_t launch_affine_rows(int interp, const float* src, float* out, const float* zeros16, const AffineParams& p, int lds_bytes, hipStream_t stream)
+hipError_t init_rows_kernels()
 {
-    const dim3 g((unsigned)((p.oW + kRowRun - 1) / kRowRun), (unsigned)((p.oH + kRowPH - 1) / kRowPH), (unsigned)((p.oD + kRowPD - 1) / kRowPD));
-    if (interp_kind(interp) == 0) hipLaunchKernelGGL(affine_rows<0>, g, dim3(256), lds_bytes, stream, src, out, zeros16, p);
-    else hipLaunchKernelGGL(affine_rows<1>, g, dim3(256), lds_bytes, stream, src, out, zeros16, p);
+    for (int kind = 0; kind < 2; ++kind)
+        for (int pd = 4; pd <= 8; pd += 4) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rows_entry(kind, pd)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+        }
+    return hipSuccess;
+}
+
+void rows_tile(int* ph, int* run) { *ph = kRowPH; *run = kRowRun; }
+
+hipError_t launch_affine_rows(int interp, int pd, const float* src, float* out, const float* zeros16, const AffineParams& p, int lds_bytes, hipStream_t stream)
+{
+    const dim3 g((unsigned)((p.oW + kRowRun - 1) / kRowRun), (unsigned)((p.oH + kRowPH - 1) / kRowPH), (unsigned)((p.oD + pd - 1) / pd));
+    hipLaunchKernelGGL(rows_entry(interp_kind(interp) == 0 ? 0 : 1, pd), g, dim3(64 * pd), lds_bytes, stream, src, out, zeros16, p);
     return hipGetLastError();
 }
 

@@ -1079,19 +1079,25 @@ bool plan_rows(const vt_volume* v, const double m[12], int flags, AffineParams* 
     const double t = m[11];
     if (!(std::fabs(t) < 1.0e9) || t != std::floor(t) || ((int64_t)t & 3) != 0) return false;
     for (int i = 0; i < 12; ++i) if (!(std::fabs(m[i]) < 1.0e9)) return false;
-    int pd, ph, run;
-    rows_tile(&pd, &ph, &run);
-    if ((v->oD + pd - 1) / pd > 65535 || (v->oH + ph - 1) / ph > 65535) return false;
+    int ph, run;
+    rows_tile(&ph, &run);
+    // the pixel tile: 8 x 8 (eight waves) where its box fits, else 4 x 8 -- [measured, 512^3, 33 degrees, one box] trilinear 0.266 -> 0.239 ms,
+    // cubic 0.369 -> 0.358 (a quarter less staged per voxel); VT_ROWS_PD=4 keeps the smaller one
     const bool cubic = is_cubic(v->interp);
     const int halo2 = cubic ? 2 : 0;
-    int L[2];
-    for (int r = 0; r < 2; ++r) {
-        const double ext = std::fabs(m[4 * r]) * (pd - 1) + std::fabs(m[4 * r + 1]) * (ph - 1);
-        if (!(ext < 200.0)) return false;
-        L[r] = (int)std::floor(ext) + 3 + halo2;          // floor(hi) - floor(lo) <= floor(ext) + 1, + 1 upper tap, + 1 slack
+    int pd = 0, L[2] = {0, 0}, lds = 0;
+    for (int cand = (v->tune.rows_pd == 4 ? 4 : 8); cand >= 4 && pd == 0; cand -= 4) {
+        if ((v->oD + cand - 1) / cand > 65535 || (v->oH + ph - 1) / ph > 65535) continue;
+        bool ok = true;
+        for (int r = 0; r < 2 && ok; ++r) {
+            const double ext = std::fabs(m[4 * r]) * (cand - 1) + std::fabs(m[4 * r + 1]) * (ph - 1);
+            ok = ext < 200.0;
+            L[r] = (int)std::floor(ext) + 3 + halo2;      // floor(hi) - floor(lo) <= floor(ext) + 1, + 1 upper tap, + 1 slack
+        }
+        lds = L[0] * L[1] * run * 4 + cand * ph * 16 * 4;  // the staged rows + 16 dwords per pixel (one wave per d, eight pixels each)
+        if (ok && lds <= 64 * 1024 && lds <= v->lds_limit) pd = cand;      // (strong minification in the (d, h) plane: the general kernels serve it)
     }
-    const int lds = L[0] * L[1] * run * 4 + 4 * ph * 16 * 4;       // the staged rows + 16 dwords per pixel (four waves x eight pixels)
-    if (lds > 64 * 1024 || lds > v->lds_limit) return false;      // (strong minification in the (d, h) plane: the general kernels serve it)
+    if (pd == 0) return false;
     plan_prepare(v, m, flags, p, plan);
     const int T[3] = {pd, ph, 1};
     set_tile_reach(p, m, T, 0);
