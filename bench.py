@@ -338,6 +338,7 @@ def main():
             rs_g = np.random.RandomState(1)
             gm = [vt.utils.transform_matrix(rotation=r, rotation_order='sxyz', center=np.divide((n, n, n), 2))
                   for r in rs_g.uniform(-180, 180, (100, 3))][:40]
+            axes = {'protocol': '16 angles (10..160 degrees) about array axis 1 / 2 through the centre, StaticVolume, device output'}
             gen = {'protocol': '40 of the 100 random sxyz rotations of tests/benchmark.py (RandomState(1)), StaticVolume, device output, second pass over the list'}
             for ip_g, handle in ((interp, sv), ('linear', None)):
                 h = handle if handle is not None else vt.StaticVolume(vol, interpolation=ip_g, device=dev)
@@ -349,9 +350,24 @@ def main():
                     h.affine(m_, output=out)
                 msg = h.timer_stop() / len(gm)
                 gen[ip_g] = {'ms': round(msg, 4), 'frac_of_8TBps': round(algo_bytes / msg / 1e6 / 8000.0, 4), 'kernel': int(h.info().last_kernel)}
+                # rotations about the other two array axes (sxyz (0, a, 0) / (0, 0, a) about the centre): the plane-quad kernel on the
+                # axis-0 <-> 1 exchanged copy, the row kernel on the plain one
+                c_ax = np.divide(np.subtract((n, n, n), 1), 2, dtype=np.float32)
+                for ax_name, rot_ax in (('axis1', lambda a: (0, a, 0)), ('axis2', lambda a: (0, 0, a))):
+                    am = [vt.utils.transform_matrix(rotation=rot_ax(float(a)), rotation_order='sxyz', center=c_ax) for a in range(10, 170, 10)]
+                    for m_ in am[:2]:
+                        h.affine(m_, output=out)
+                    h.synchronize()
+                    h.timer_start()
+                    for m_ in am:
+                        h.affine(m_, output=out)
+                    ms_ax = h.timer_stop() / len(am)
+                    axes.setdefault(ax_name, {})[ip_g] = {'ms': round(ms_ax, 4), 'frac_of_8TBps': round(algo_bytes / ms_ax / 1e6 / 8000.0, 4),
+                                                          'kernel': int(h.info().last_kernel)}
                 if handle is None:
                     h.close()
             extra['general_rotations'] = gen
+            extra['single_axis_rotations'] = axes
         pf_ms = float(info.prefilter_ms)
         if pf_ms > 0:
             # the first prefilter of a process also pays for loading its kernels; a second resident volume shows the
