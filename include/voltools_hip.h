@@ -93,7 +93,7 @@ typedef struct vt_volume_info {
     int32_t interp;
     int32_t depth, height, width;      /* source dims as passed to create (including any slab halo planes; the mirror padding of VT_EDGE_SCIPY handles is not counted) */
     int32_t out_depth, out_height, out_width;
-    int32_t last_kernel;               /* 0 none, 1 direct, 2 tiled (boxes), 3 tiled axis-0-separable, 4 marching, 5 marching on plane pairs, 6 tiled (packed footprints), 7 fused projection, 8 marching on plane quads, 9 lane-block tiles (general matrices) */
+    int32_t last_kernel;               /* 0 none, 1 direct, 2 tiled (boxes), 3 tiled axis-0-separable, 4 marching, 5 marching on plane pairs, 6 tiled (packed footprints), 7 fused projection (vt_volume_project), 8 marching on plane quads, 9 lane-block tiles (general matrices), 10 source rows along w (maps that leave axis 2 alone) */
     int32_t last_tile[3];              /* output tile (TD, TH, TW) of the last tiled launch (marching: G, TH, TW) */
     int32_t last_lds_dims[3];          /* staged source box (Lz, Ly, Lx) (marching: ring slots, Ly, Lx)    */
     int32_t last_lds_bytes;

@@ -11,6 +11,8 @@ What is recorded (inputs are re-creatable from the stored seeds/parameters; outp
   volumes_m12.npz .... a seeded 48x52x56 float32 volume (large enough to have voxels 12 samples from every
                        face) and the reference CPU path's filt_bspline outputs for three matrices: pins the
                        prefiltered interpolations at the SURVEY 8c tolerance, 2e-6 at margin 12.
+  launch_dims.npz .... outputs of the reference's compute_prefilter_workgroup_dims (utils/general.py:9-33; a pure function)
+                       for a list of shapes: pins the informational helper of the same name.
   volumes.npz ........ a seeded 20x24x28 float32 volume and the outputs of
                        voltools.affine / voltools.transform / StaticVolume(device='cpu')
                        (/root/reference/voltools/transforms.py:109-162, volume.py:93-101) for
@@ -146,8 +148,21 @@ def golden_volumes_m12():
     print('volumes_m12:', len(out), 'arrays,', os.path.getsize(os.path.join(HERE, 'volumes_m12.npz')) // 1024, 'KiB')
 
 
+def golden_launch_dims():
+    shapes = [(64, 64, 64), (200, 200, 200), (512, 512, 512), (48, 96, 40), (1, 5, 7), (30, 20, 12), (1024, 1024, 1024),
+              (96, 64, 160), (250, 250, 250), (2, 3, 130), (128, 4, 36), (20, 24, 28)]
+    grids, blocks = [], []
+    for s in shapes:
+        g, b = vt.utils.compute_prefilter_workgroup_dims(s)
+        grids.append(g); blocks.append(b)
+    np.savez_compressed(os.path.join(HERE, 'launch_dims.npz'), shapes=np.array(shapes), grids=np.array(grids), blocks=np.array(blocks))
+    print('launch_dims:', len(shapes))
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['matrices', 'volumes', 'volumes_m12']
+    which = sys.argv[1:] or ['matrices', 'volumes', 'volumes_m12', 'launch_dims']
+    if 'launch_dims' in which:
+        golden_launch_dims()
     if 'matrices' in which:
         golden_matrices()
     if 'volumes' in which:

@@ -59,5 +59,29 @@ def test_api_surface_and_errors():
         assert hasattr(vt, name)
     for name in ('transform_matrix', 'rotation_matrix', 'scale_matrix', 'shear_matrix', 'translation_matrix',
                  'get_available_devices', 'switch_to_device', 'compute_post_transform_dimensions',
+                 'compute_prefilter_workgroup_dims', 'compute_elementwise_launch_dims',
                  'AVAILABLE_ROTATIONS', 'AVAILABLE_UNITS'):
         assert hasattr(vt.utils, name)
+
+
+def test_informational_launch_geometry_helpers():
+    """The reference exports its CUDA launch-geometry helpers from voltools.utils (utils/__init__.py:4-5, general.py:9-58); the names exist
+    here with the same results (the prefilter one against outputs of the reference itself, tests/golden/launch_dims.npz; the elementwise
+    one against the reference's formula evaluated by hand for wavefront size 64 and 256 compute units)."""
+    import os
+    from voltools_amd.utils import compute_elementwise_launch_dims, compute_prefilter_workgroup_dims
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'launch_dims.npz'))
+    for shape, grids, blocks in zip(g['shapes'], g['grids'], g['blocks']):
+        got_g, got_b = compute_prefilter_workgroup_dims(tuple(int(n) for n in shape))
+        assert np.array_equal(np.array(got_g), grids) and np.array_equal(np.array(got_b), blocks), shape
+    try:
+        from voltools_amd import _native
+        cus = _native.device_props(0)[0] if _native.device_count() > 0 else 256
+    except OSError:
+        cus = 256
+    cap = 32 * cus
+    assert compute_elementwise_launch_dims((1, 1, 1)) == ((1, 1, 1), (64, 1, 1))                    # fewer voxels than a wavefront
+    assert compute_elementwise_launch_dims((3, 4, 11)) == ((3, 1, 1), (64, 1, 1))                   # one wavefront per 64 voxels
+    n = cap * 64 + 1
+    assert compute_elementwise_launch_dims((1, 1, n)) == ((cap, 1, 1), (128, 1, 1))                 # all blocks, two wavefronts each
+    assert compute_elementwise_launch_dims((512, 512, 512)) == ((cap, 1, 1), (128, 1, 1))           # the grid-stride regime

@@ -146,8 +146,8 @@ def test_huge_cubic_sweep_and_axis_exchanges(interp, huge):
             err = float(np.abs(out.get_planes(d0, d0 + 8) - want).max())
             assert err <= tol, (interp, ang, d0, err)
     # rotations about axis 1 march on an exchanged resident copy ([y][z][x]), rotations about axis 2 (integer offset) run the row kernel on the
-    # plain one (kind 7) and, with VT_FORCE_XSWAP, march on the [x][y][z] copy; all against the general-matrix kernels
-    for order_rot, want_kernel in (((0, 33, 0), 8), ((0, 0, 33), 7)):
+    # plain one (kind 10) and, with VT_FORCE_XSWAP, march on the [x][y][z] copy; all against the general-matrix kernels
+    for order_rot, want_kernel in (((0, 33, 0), 8), ((0, 0, 33), 10)):
         m = vt.utils.transform_matrix(rotation=order_rot, rotation_order='sxyz', center=centre())
         sv.affine(m, output=out)
         k = int(sv.info().last_kernel)
@@ -156,7 +156,7 @@ def test_huge_cubic_sweep_and_axis_exchanges(interp, huge):
         sv.synchronize()
         assert k == want_kernel and k2 in (2, 6, 9), (order_rot, k, k2)
         assert max_abs_diff(torch, t_out, t_out2) <= tol, (interp, order_rot)
-        if want_kernel == 7:
+        if want_kernel == 10:
             sv.affine(m, output=out, _flags=_native.FORCE_XSWAP)
             assert int(sv.info().last_kernel) == 8
             sv.synchronize()

@@ -1069,7 +1069,7 @@ def test_reoriented_copies_are_built_at_the_fourth_request_only():
 @pytest.mark.parametrize('interp', ALL_INTERPS)
 @pytest.mark.parametrize('shape', [(70, 66, 72), (33, 47, 50), (5, 9, 130), (64, 64, 64)])
 def test_row_kernel_for_maps_that_leave_axis_2_alone(interp, shape):
-    """Kind 7 (vt_kernels_rows.hip): rotations about axis 2 and any (d, h) affine map with an integer axis-2 offset that is a multiple
+    """Kind 10 (vt_kernels_rows.hip): rotations about axis 2 and any (d, h) affine map with an integer axis-2 offset that is a multiple
     of four.  Against the oracle at the family's tolerance and BIT-IDENTICAL to affine_direct (same chain of operations, the x-sum of the
     cubic stencil formed once in the x-convolved copy); widths that are no multiple of 64 or 4, offsets that push rows over either end,
     keep_outside, and the offsets the kernel does not take (fractional, not a multiple of four) going elsewhere."""
@@ -1092,18 +1092,18 @@ def test_row_kernel_for_maps_that_leave_axis_2_alone(interp, shape):
         want = oracle.affine(vol, m, interp)
         got = sv.affine(m, _flags=_native.FORCE_TILED)
         k = sv.info().last_kernel
-        assert (k == 7) == takes, (interp, shape, name, k)
+        assert (k == 10) == takes, (interp, shape, name, k)
         assert np.abs(got - want).max() <= TOL[interp], (interp, shape, name, k)
         direct = sv.affine(m, _flags=_native.FORCE_DIRECT)
         if takes:
             assert np.array_equal(got, direct), (interp, shape, name, float(np.abs(got - direct).max()))
             other = sv.affine(m, _flags=_native.FORCE_TILED | _native.NO_ROWS)
-            assert sv.info().last_kernel != 7
+            assert sv.info().last_kernel != 10
             assert np.abs(other - want).max() <= TOL[interp]
             init = rand_vol(shape, 52)
             kept = init.copy()
             sv.affine(m, output=kept, keep_outside=True, _flags=_native.FORCE_TILED)
-            assert sv.info().last_kernel == 7
+            assert sv.info().last_kernel == 10
             outside = (got == 0) & (direct == 0) & (np.abs(want) == 0)
             kd = init.copy()
             sv.affine(m, output=kd, keep_outside=True, _flags=_native.FORCE_DIRECT)

@@ -142,7 +142,7 @@ def test_nonfinite_placement(interp, badval):
             got_bad = ~np.isfinite(got)
             allowed_missing = np.zeros(SHAPE, bool)
             if k in (7, 8):
-                # (kind 7, the row kernel: the same along axis 2)
+                # (kind 10, the row kernel: the same along axis 2)
                 # KIND 3 / KIND 4 (on the plain copy, or on an axis-exchanged one for rotations about axis 1 / 2): along the marching axis `a`
                 # (row a of the matrix is a unit row with an integer offset) trilinear output slice d reads source slice d + off only, the
                 # cubic one slices d + off - 1 .. d + off + 1 (through the z-convolved copy); the oracle also multiplies the next slice

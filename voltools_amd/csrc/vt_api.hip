@@ -607,7 +607,7 @@ int try_rows(vt_volume* v, const double m[12], int flags, AffineParams* p, TileP
     std::memset(&ps, 0, sizeof(ps));
     TilePlan plans = TilePlan();
     plans.kind = 0;
-    if (!plan_rows(v, m, flags, &ps, &plans) || plans.kind != 7) return 0;
+    if (!plan_rows(v, m, flags, &ps, &plans) || plans.kind != 10) return 0;
     if (is_cubic(v->interp) && !v->d_src_xe) {
         if (v->xe_retry_in > 0) { --v->xe_retry_in; return 0; }
         const size_t bytes = (size_t)v->D * v->H * v->P * sizeof(float);
@@ -742,7 +742,7 @@ int launch_planned(vt_volume* v, const TilePlan& plan, const AffineParams& p, co
     } else if (plan.kind == 4) {
         VT_HIP(launch_affine_march(plan.cfg, v->interp, ori.src_plain, d_out, p, plan.grid, plan.lds_bytes, v->stream));
 #endif
-    } else if (plan.kind == 7) {
+    } else if (plan.kind == 10) {
         VT_HIP(launch_affine_rows(v->interp, plan.td, ori.src_plain, d_out, v->d_zeros, p, plan.lds_bytes, v->stream));
     } else if (plan.kind >= 2) {
         VT_HIP(launch_affine_tiled(plan.cfg, v->interp, plan.kind == 3, ori.src_plain, d_out, v->d_zeros, p, plan.grid, plan.lds_bytes, v->stream));

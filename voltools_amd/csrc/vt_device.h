@@ -183,6 +183,8 @@ __device__ __forceinline__ float cubic_gather_b64(RowAddr row, int par, const fl
 #pragma unroll
         for (int bb = 0; bb < 4; ++bb) {
             const unsigned ra = row(c, bb);
+            // (no wait states needed around this statement: its inputs are address VGPRs from integer VALU instructions, which the hardware
+            //  interlocks; see the note at vt_kernels_block.hip: lds_read_b64)
             asm volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:8\n\tds_read_b64 %2, %4"
                          : "=&v"(r[3 * bb]), "=&v"(r[3 * bb + 1]), "=&v"(r[3 * bb + 2]) : "v"(ra), "v"(ra + off3));
         }

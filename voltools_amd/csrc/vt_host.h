@@ -8,7 +8,8 @@
 
 // Experiment overrides, read from the environment once per handle (vt_volume_create) -- never on the per-call path.
 // None is needed in production; the A/B runs quoted in DESIGN.md (tools/march_ab.py --env) and a few parity tests use them to reach
-// planner alternatives.  The product build reads 15 of them; the rest belong to the test build (VT_LEGACY) and the ablation build.
+// planner alternatives.  read() below is the list: the knobs outside its #ifdef blocks are read by the product build, the others by the
+// test build (VT_LEGACY: round 1's kernels and the settled A/Bs of round 3) or the ablation build (VT_EXPERIMENTS).
 struct Tuning {
     int tile = -1;                 // VT_TILE: force tile configuration (index into the kernel family's table)
     int la = 0;                    // VT_LA: planes / pairs staged ahead by the marching kernels
@@ -30,10 +31,10 @@ struct Tuning {
     bool no_proj_cache = false;    // VT_NO_PROJ_CACHE: every projection recomputes the weighted plane sum (test of the cache)
     int quad_pingpong = 1;         // VT_QUAD_PINGPONG: 1 = every other launch of a handle walks the chunk layers from the last to the first; 0 / 2 = never / always
     int quad_zid = 1;              // VT_QUAD_ZID=0: trilinear launches with fz == 0 keep the two-plane kernel (round-3 A/B)
-int reorient = 4;              // VT_REORIENT: general matrices sample the resident copy whose rows follow the output's w axis, built at the n-th request (0 = never)
+    int reorient = 4;              // VT_REORIENT: general matrices sample the resident copy whose rows follow the output's w axis, built at the n-th request (0 = never)
     int rows_pd = 8;               // VT_ROWS_PD=4: the row kernel's pixel tile is 4 x 8 (four waves) instead of 8 x 8
-    int rows = 1;                  // VT_ROWS=0: maps that leave axis 2 alone take the axis-exchange path instead of the row kernel (kind 7)
-        int quad_zfir = 1;             // VT_QUAD_ZFIR=0: cubic launches with fz == 0 keep the four-plane kernel (round-4 A/B: the z-convolved copy)
+    int rows = 1;                  // VT_ROWS=0: maps that leave axis 2 alone take the axis-exchange path instead of the row kernel (kind 10)
+    int quad_zfir = 1;             // VT_QUAD_ZFIR=0: cubic launches with fz == 0 keep the four-plane kernel (round-4 A/B: the z-convolved copy)
     int zid_dch = 0;               // VT_ZID_DCH: chunk depth of the integer-offset trilinear kernel (0 = the trilinear default)
     int quad_nt = -1;              // VT_QUAD_NT: 1 / 0 = nontemporal / plain output stores of the plane-quad kernel, -1 = planner's choice
     bool no_block = false;         // VT_NO_BLOCK_KERNEL: general matrices on the round-1 box / packed kernels
@@ -116,7 +117,7 @@ struct vt_volume {
     float* d_src_r_q = nullptr;
     float* d_src_x_q = nullptr;
     size_t quad_bytes[4] = {0, 0, 0, 0};   // allocation sizes of the four quad copies (vt_volume_info)
-    float* d_src_xe = nullptr;         // plain-layout copy convolved along axis 2 with the cubic weights of fraction 0 (row kernel, kind 7, cubic; vt_kernels_rows.hip: relayout_xfir); lazy
+    float* d_src_xe = nullptr;         // plain-layout copy convolved along axis 2 with the cubic weights of fraction 0 (row kernel, kind 10, cubic; vt_kernels_rows.hip: relayout_xfir); lazy
     float* d_src_qe[4] = {nullptr, nullptr, nullptr, nullptr};   // plane-quad copies of the Z-CONVOLVED volume per orientation (cubic launches with an integer axis-0 offset; vt_kernels_quad.hip: relayout_zquad_fir); lazy
     size_t quade_bytes[4] = {0, 0, 0, 0};
     int reorient_asked[3] = {0, 0, 0};   // general matrices that asked for the copy whose fastest axis is source axis 0 / 1 (vt_api.hip: try_general_reorient)

@@ -124,7 +124,8 @@ struct PackGeom {
 
 struct TilePlan {
     int kind;            // 1 direct, 2 tiled, 3 tiled axis-0-separable, 4 marching, 5 marching on plane pairs, 6 tiled with packed footprints,
-                         // 7 source rows along w (maps that leave axis 2 alone), 8 marching on plane quads, 9 lane-block tiles (cfg = row-stride index)
+                         // 7 reserved (vt_volume_info: fused projection), 8 marching on plane quads, 9 lane-block tiles (cfg = row-stride index),
+                         // 10 source rows along w (maps that leave axis 2 alone)
     int cfg;             // index into the tile table
     int td, th, tw;
     int lds_bytes;
@@ -217,7 +218,7 @@ void quad_config(int idx, int* th, int* tw, int* nt);
 int quad_blocks_per_cu(int cfg, int interp, int lds_bytes, bool zid = false);
 hipError_t init_quad_kernels();
 hipError_t launch_relayout_zquad(const float* src, float* dst, int D, int H, int W, int P, int Pq, hipStream_t stream);
-// vt_kernels_rows.hip (kind 7: maps that leave axis 2 alone)
+// vt_kernels_rows.hip (kind 10: maps that leave axis 2 alone)
 hipError_t launch_relayout_xfir(const float* src, float* dst, int D, int H, int W, int P, bool simple, hipStream_t stream);
 hipError_t init_rows_kernels();
 void rows_tile(int* ph, int* run);

@@ -38,6 +38,12 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int kBlkTD = 8, kBlkTW = 16;         // tile depth and width; the height is a template parameter: 16 (two workgroups per CU) or 8 (four)
 constexpr int block_max_it(int th) { return th == 16 ? 20 : 13; }      // staging vectors per thread: boxes up to 80 KiB / 52 KiB (four workgroups per CU up to 40 KiB, three beyond)
 
+// (Inline asm and hazards: the compiler's hazard recogniser does not look into asm statements -- vt_kernels_rows.hip met that with a
+//  v_readfirstlane_b32.  This statement is safe without wait states: its only register input is the address VGPR, written by plain
+//  integer VALU instructions, and a VALU result feeding a later instruction's VGPR operand is interlocked by the hardware (the gfx950
+//  software hazards concern VALU-written SGPR / VCC / EXEC / M0 read by lane-access, VMEM or LDS-DMA instructions, trans and
+//  double-precision results read by the very next VALU, and v_readlane / v_writelane lane selects: none applies to a ds_read address);
+//  the result is consumed only behind the counted s_waitcnt lgkmcnt of VT_BLK_WAIT, whose "+v" operands tie it to the sums.)
 template <int OFF>
 __device__ __forceinline__ void lds_read_b64(v2f& r, unsigned a)
 {

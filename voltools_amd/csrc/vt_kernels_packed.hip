@@ -24,6 +24,8 @@ constexpr int kPackRowsMax = 1024;    // (z, y) rows of the bounding box
 // 16 bytes per lane, global memory -> LDS at lds_addr + 16 * lane, without a register round trip.
 // Written as inline assembly: with the builtin, hipcc 7.2 merges the M0 initialisations of an unrolled sequence of
 // direct-to-LDS loads and every load lands on the first destination.  The caller waits with s_waitcnt vmcnt(0).
+// (Hazards inside the statement: M0 is written by a SALU instruction and read by the LDS-DMA load that follows -- one wait state,
+// the s_nop; the address VGPR pair comes from VALU instructions, interlocked by the hardware.)
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"      // "m0 is reserved": exactly why it is listed as clobbered
 __device__ __forceinline__ void lds_dma16(const float* g, unsigned lds_addr)

@@ -299,12 +299,15 @@ __global__ __launch_bounds__(NT, (KIND == 4 && TH * TW == 2 * NT) ? 4 : 1) void 
     int o1, o2;
     {
         const int f1 = (int)floor(lo[1]), f2 = (int)floor(lo[2]);
-        // (s_nop on both sides: the compiler's hazard recogniser does not look into an asm statement -- it neither waits between the vector
-        //  instruction that produces f1 / f2 (v_cvt_i32_f64, the instruction right in front) and this lane read of it, nor between the
-        //  scalar result and a scalar instruction reading it.  The row kernel, vt_kernels_rows.hip, got a stale origin in some waves and
-        //  launch-to-launch differences from exactly this pattern, until it used the builtin.)
-        asm volatile("s_nop 1\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 4" : "=s"(o1) : "v"(f1));
-        asm volatile("s_nop 1\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 4" : "=s"(o2) : "v"(f2));
+        // The builtin on a value the compiler can no longer prove uniform (it passed through an empty asm statement): the compiler emits
+        // v_readfirstlane_b32 itself, with the wait states its hazard recogniser knows.  (Round 4 wrote the instruction as inline asm with
+        // hand-counted s_nop on both sides -- the recogniser does not look into asm statements, and the row kernel, vt_kernels_rows.hip, got
+        // stale origins from that pattern without the s_nop.  The builtin alone, on a value known to be uniform, is dropped, and both floors
+        // then sit in vector registers for the whole kernel.)
+        int g1 = f1, g2 = f2;
+        asm volatile("" : "+v"(g1), "+v"(g2));
+        o1 = __builtin_amdgcn_readfirstlane(g1);
+        o2 = __builtin_amdgcn_readfirstlane(g2);
         o1 -= HALO;
         o2 -= HALO;                               // every position is its own 16-byte vector: no alignment of the origin
     }

@@ -1,4 +1,4 @@
-// vt_kernels_rows.hip -- kind 7: maps that leave axis 2 alone, src_w = w + t with an integer t that is a multiple of four
+// vt_kernels_rows.hip -- kind 10: maps that leave axis 2 alone, src_w = w + t with an integer t that is a multiple of four
 // ([a b 0 t0; c e 0 t1; 0 0 1 t]: every rotation about axis 2 through the default centre, scaled / sheared or not in the (d, h) plane).
 //
 // The resident plain layout [z][y][x] is, for these maps, what the plane-quad copy is for rotations about axis 0: the axis the map

@@ -749,6 +749,10 @@ void pick_packed_tile(PlanCtx& c, const double inv[9], PackedChoice* out)
         L[2] = (L[2] + 3 + 3) & ~3;
         const int rows = L[0] * L[1];
         if (rows > packed_rows_max() || L[2] > 4000) continue;
+        // the kernel stages a box inside the volume through ONE buffer descriptor based at the box origin: the 32-bit byte offset of the
+        // box's last row must stay below the descriptor's 2^31 - 1 records (planes of 4096 x 4128 floats reach that at 32 box planes;
+        // plan_block has the same bound)
+        if ((int64_t)L[0] * v->H * v->P * 4 >= 0x7fffffffLL) continue;
         for (int i = 0; i < 9; ++i) g.inv[i] = inv[i];
         for (int cc = 0; cc < 3; ++cc) g.cst[cc] = inv[3 * cc] * neg[0] + inv[3 * cc + 1] * neg[1] + inv[3 * cc + 2] * neg[2];
         g.T[0] = T[0]; g.T[1] = T[1]; g.T[2] = T[2];
@@ -1063,7 +1067,7 @@ static void plan_prepare(const vt_volume* v, const double m[12], int flags, Affi
 }
 
 // ---------------------------------------------------------------------------------------------------
-// rows: maps that leave axis 2 alone (kind 7, vt_kernels_rows.hip).  Planned by do_affine ahead of the axis exchanges, on the handle's
+// rows: maps that leave axis 2 alone (kind 10, vt_kernels_rows.hip).  Planned by do_affine ahead of the axis exchanges, on the handle's
 // own orientation only; false = not this class / does not fit, the plan is untouched (kind 0) and the usual dispatch follows.
 // ---------------------------------------------------------------------------------------------------
 bool plan_rows(const vt_volume* v, const double m[12], int flags, AffineParams* p, TilePlan* plan)
@@ -1107,7 +1111,7 @@ bool plan_rows(const vt_volume* v, const double m[12], int flags, AffineParams* 
     p->fz = 0.0f;
     p->flags = (flags & VT_KEEP_OUTSIDE);
     if (v->interp == VT_BSPLINE_SIMPLE || v->interp == VT_FILT_BSPLINE_SIMPLE) p->flags |= (1 << 18);
-    plan->kind = 7; plan->cfg = 0; plan->td = pd; plan->th = ph; plan->tw = run;
+    plan->kind = 10; plan->cfg = 0; plan->td = pd; plan->th = ph; plan->tw = run;
     plan->lds_bytes = lds;
     plan->grid = (int)std::min<int64_t>(0x7fffffff, (int64_t)((v->oW + run - 1) / run) * ((v->oH + ph - 1) / ph) * ((v->oD + pd - 1) / pd));
     plan->blocks_per_cu = std::max(1, std::min(8, (160 * 1024) / std::max(1, lds)));
