@@ -94,7 +94,7 @@ def test_tiled_and_direct_match_oracle(interp, mname, shape):
         # rotations about axis 1 / 2 march along an axis-exchanged resident copy
         assert 8 in kernels and (not LEGACY or ((4 in kernels) if interp == 'linear' else (5 in kernels and 4 in kernels)))
     if mname == 'rot_axis2':
-        assert 7 in kernels                          # ... and, with an integer offset along axis 2, the row kernel serves them on the plain copy
+        assert 10 in kernels                         # ... and, with an integer offset along axis 2, the row kernel serves them on the plain copy
     if mname in ('identity', 'shift_int', 'shift_frac', 'rot_inplane45', 'rot_inplane100', 'rot_inplane260'):
         assert 8 in kernels
         if LEGACY:
@@ -1113,3 +1113,46 @@ def test_row_kernel_for_maps_that_leave_axis_2_alone(interp, shape):
         assert sv.release_copies() > 0 and sv.info().resident_bytes == base
         assert np.array_equal(sv.affine(rot, _flags=_native.FORCE_TILED), sv.affine(rot, _flags=_native.FORCE_DIRECT))
     sv.close()
+
+
+@pytest.mark.parametrize('interp', ['linear'])
+def test_packed_span_kernel_forms_and_rim_paths(interp, monkeypatch):
+    """Round 5's trilinear packed-span kernel (vt_kernels_span.hip, kind 6) in both forms -- single buffer (`affine_span`) and wave-specialised
+    with two buffers (`affine_span_ws`, VT_SPAN_PIPE=1: the knob is read when a handle is created) -- on shapes that exercise what is new:
+    rim tiles on every face (store masks ahead of the gather, bounds tests by dividing the staging offset), partial tiles at the output's
+    far ends, exact-integer coordinates (quarter turns: the Q32.32 terms must round, not truncate), keep_outside, a reshaped output.
+    Against the oracle at the family's tolerance; the two forms against each other bit for bit (same arithmetic per voxel)."""
+    shapes = [(70, 66, 72), (130, 40, 64), (48, 200, 130), (97, 65, 200)]
+    flags = _native.FORCE_TILED | _native.NO_ZSEP | _native.FORCE_PACKED
+    for shape in shapes:
+        vol = rand_vol(shape, 77)
+        c = centre(shape)
+        mats = {
+            'general': vt.utils.transform_matrix(rotation=(25.0, -40.0, 70.0), rotation_order='sxyz', translation=(1.5, -2.0, 0.75), center=c),
+            'general_scaled': vt.utils.transform_matrix(rotation=(-110.0, 33.0, 12.0), scale=(0.8, 1.1, 1.3), rotation_order='rzxz', center=c),
+            'quarter': vt.utils.transform_matrix(rotation=(90.0, 180.0, 270.0), rotation_order='sxyz', center=c),
+            'quarter2': vt.utils.transform_matrix(rotation=(270.0, 90.0, 0.0), rotation_order='sxyz', center=c),
+            'far_corner': vt.utils.transform_matrix(rotation=(10.0, 20.0, 30.0), rotation_order='sxyz', translation=(shape[0] * 0.4, -shape[1] * 0.3, 5.0), center=c),
+        }
+        got = {}
+        for pipe in ('0', '1'):
+            monkeypatch.setenv('VT_SPAN_PIPE', pipe)
+            sv = vt.StaticVolume(vol, interpolation=interp, device='gpu:0')
+            for name, m in mats.items():
+                want = oracle.affine(vol, m, interp)
+                out = sv.affine(m, _flags=flags)
+                k = sv.info().last_kernel
+                assert k in (6, 2), (shape, name, pipe, k)               # (tiny boxes: the span family refuses volumes smaller than its box)
+                assert np.abs(out - want).max() <= TOL[interp], (shape, name, pipe, k, float(np.abs(out - want).max()))
+                got[(name, pipe)] = (out, k)
+                init = rand_vol(shape, 78)
+                kept = init.copy()
+                sv.affine(m, output=kept, keep_outside=True, _flags=flags)
+                kd = init.copy()
+                sv.affine(m, output=kd, keep_outside=True, _flags=_native.FORCE_DIRECT)
+                assert np.array_equal(kept == init, kd == init) or np.abs(kept - kd).max() <= TOL[interp], (shape, name, pipe)
+            sv.close()
+        for name in mats:
+            (a, ka), (b, kb) = got[(name, '0')], got[(name, '1')]
+            if ka == 6 and kb == 6:
+                assert np.array_equal(a, b), (shape, name, float(np.abs(a - b).max()))

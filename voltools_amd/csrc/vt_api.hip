@@ -266,6 +266,7 @@ int init_device(int dev)
             if (g_init_err[dev] == hipSuccess) g_init_err[dev] = init_quad_kernels();
             if (g_init_err[dev] == hipSuccess) g_init_err[dev] = init_block_kernels();
             if (g_init_err[dev] == hipSuccess) g_init_err[dev] = init_rows_kernels();
+            if (g_init_err[dev] == hipSuccess) g_init_err[dev] = init_span_kernels();
             hipDeviceProp_t prop;
             if (g_init_err[dev] == hipSuccess) g_init_err[dev] = hipGetDeviceProperties(&prop, dev);
             if (g_init_err[dev] == hipSuccess) {
@@ -736,6 +737,8 @@ int launch_planned(vt_volume* v, const TilePlan& plan, const AffineParams& p, co
             VT_HIP(launch_affine_block(plan.cfg, plan.th, v->interp, ori.src_plain, d_out, v->d_zeros, v->d_queue, p, plan.geo, plan.grid, plan.lds_bytes, v->stream));
 #endif
         }
+        else if (!is_cubic(v->interp) && v->tune.span != 0)
+            VT_HIP(launch_affine_span(plan.cfg, ori.src_plain, d_out, v->d_zeros, v->d_queue, p, plan.geo, plan.grid, plan.lds_bytes, v->stream));
         else
             VT_HIP(launch_affine_packed(plan.cfg, v->interp, ori.src_plain, d_out, v->d_zeros, v->d_queue, p, plan.geo, plan.grid, plan.lds_bytes, v->stream));
 #ifdef VT_LEGACY

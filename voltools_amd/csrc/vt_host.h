@@ -23,6 +23,9 @@ struct Tuning {
     bool exp_noload = false;
     bool exp_nolds = false;
     bool exp_noloop = false;
+    bool exp_stamps = false;       // VT_EXP_STAMPS (ablation build): phase timers of the span kernel, written over the first floats of the output
+    bool exp_notiles = false;      // VT_EXP_NOTILES (ablation build): the span kernel's workgroups do their set-up and leave
+    bool exp_static = false;       // VT_EXP_STATIC (ablation build): persistent kernels stride through their tile ids instead of fetching them from the queue
     int quad_rows = -2;            // VT_QUAD_ROWS: -1 = rows packed back to back, 0..15 = force the row stride S of the bank-aware placement, -2 = planner
     int quad_grid2d = 1;           // VT_QUAD_GRID2D=0: 1-D grid with XCD-contiguous ids over all chunks (round-2 A/B)
     int quad_reverse = -1;         // VT_QUAD_REVERSE: 1 / 0 = the 2-D grid walks the in-plane tiles in descending / ascending order, -1 = planner
@@ -43,6 +46,8 @@ struct Tuning {
     bool block_no_trim = false;    // VT_BLOCK_NO_TRIM: the lane-block kernel stages whole boxes (A/B of the footprint trimming)
     int block_min = 240;           // VT_BLOCK_MIN: smallest output (cube edge) that general cubic launches take to the lane-block kernel
     int block_pad = -1;            // VT_BLOCK_PAD: plane-stride padding in floats instead of the bank model's choice
+    int span = 1;                  // VT_SPAN=0: trilinear general matrices on round 1's packed-footprint kernel (vt_kernels_packed.hip) instead of round 5's (A/B)
+    int span_pipe = 0;             // VT_SPAN_PIPE: 1 / 0 = trilinear general matrices on the software-pipelined / the single-buffer form of the packed-span kernel, -1 = the planner's cost model
     int block_th = 8;              // VT_BLOCK_TH: tile height of the lane-block kernel: 8 (8 x 8 x 16 tiles, four workgroups per CU; boxes beyond 40 KiB fall back to 16) or 16 (8 x 16 x 16, two per CU)
     void read()
     {
@@ -64,6 +69,9 @@ struct Tuning {
         exp_noload = std::getenv("VT_EXP_NOLOAD") != nullptr;
         exp_nolds = std::getenv("VT_EXP_NOLDS") != nullptr;
         exp_noloop = std::getenv("VT_EXP_NOLOOP") != nullptr;
+        exp_static = std::getenv("VT_EXP_STATIC") != nullptr;
+        exp_notiles = std::getenv("VT_EXP_NOTILES") != nullptr;
+        exp_stamps = std::getenv("VT_EXP_STAMPS") != nullptr;
 #endif
         quad_nt = num("VT_QUAD_NT", -1);
 #ifdef VT_LEGACY              // settled A/Bs of round 3 and the allocation-failure hook: test build only (the product build keeps the defaults)
@@ -86,6 +94,8 @@ struct Tuning {
         block_linear = std::getenv("VT_BLOCK_LINEAR") != nullptr;
         block_pad = num("VT_BLOCK_PAD", -1);
         block_th = num("VT_BLOCK_TH", 8) == 16 ? 16 : 8;
+        span_pipe = num("VT_SPAN_PIPE", 0);
+        span = num("VT_SPAN", 1);
         block_min = std::max(1, num("VT_BLOCK_MIN", 240));
         block_no_trim = std::getenv("VT_BLOCK_NO_TRIM") != nullptr;
     }

@@ -242,6 +242,15 @@ int packed_vectors_max();
 hipError_t init_packed_kernels();
 hipError_t launch_affine_packed(int cfg, int interp, const float* src, float* out, const float* zeros16, int* queue,
                                 const AffineParams& p, const PackGeom& geo, int grid, int lds_bytes, hipStream_t stream);
+// trilinear packed-span kernel of round 5 (vt_kernels_span.hip)
+int span_config_count();
+void span_config(int idx, int* td, int* th, int* tw);
+int span_rows_max();
+bool span_config_pipelined(int idx);      // two footprint buffers: LDS = table + 2 x capacity
+int span_vectors_max();
+hipError_t init_span_kernels();
+hipError_t launch_affine_span(int cfg, const float* src, float* out, const float* zeros16, int* queue,
+                              const AffineParams& p, const PackGeom& geo, int grid, int lds_bytes, hipStream_t stream);
 int march_rows_max();
 int march_max_it();
 int interp_kind(int interp);

@@ -262,7 +262,7 @@ void set_axis0_split(AffineParams* p, const double m[12])
 int experiment_flags(const vt_volume* v)
 {
     return (v->tune.exp_nostore ? (1 << 21) : 0) | (v->tune.exp_noload ? (1 << 22) : 0) | (v->tune.exp_nolds ? (1 << 26) : 0) |
-           (v->tune.exp_noloop ? (1 << 27) : 0);
+           (v->tune.exp_noloop ? (1 << 27) : 0) | (v->tune.exp_static ? (1 << 28) : 0) | (v->tune.exp_stamps ? (1 << 29) : 0) | (v->tune.exp_notiles ? (1 << 30) : 0);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -721,10 +721,14 @@ void pick_packed_tile(PlanCtx& c, const double inv[9], PackedChoice* out)
     const double* m = c.m;
     double best = 1e300;
     out->found = false;
-    for (int cfg = 0; cfg < packed_config_count(); ++cfg) {
+    // trilinear: round 5's kernel (vt_kernels_span.hip: 16-byte table entries, whole waves stage, at most 128 VGPRs = four workgroups per
+    // CU); cubic (planned only when forced): round 1's (vt_kernels_packed.hip)
+    const bool span = !c.cubic && v->tune.span != 0;
+    const int ncfg = span ? span_config_count() : packed_config_count();
+    for (int cfg = 0; cfg < ncfg; ++cfg) {
         if (v->tune.tile >= 0 && cfg != v->tune.tile) continue;
         int T[3];
-        packed_config(cfg, &T[0], &T[1], &T[2]);
+        if (span) span_config(cfg, &T[0], &T[1], &T[2]); else packed_config(cfg, &T[0], &T[1], &T[2]);
         // too few tiles to amortise the per-workgroup set-up (see `enough` in plan_packed): do not even plan it -- the span
         // summation below is the most expensive part of the host-side planning (~20 us)
         const int64_t tiles_c = (int64_t)((v->oD + T[0] - 1) / T[0]) * ((v->oH + T[1] - 1) / T[1]) * ((v->oW + T[2] - 1) / T[2]);
@@ -743,16 +747,22 @@ void pick_packed_tile(PlanCtx& c, const double inv[9], PackedChoice* out)
             }
             if (!(ext < 1000.0)) { ok = false; break; }
             g.ext[r] = ext;
-            L[r] = (int)std::floor(ext) + 3 + c.halo2;
+            // (span kernel: its box origin lies 4e-9 below the tile's lowest coordinate and its Q32.32 coordinates carry 2e-9 of rounding,
+            //  vt_kernels_span.hip: fx64 -- an extent within 1e-8 of an integer needs the next row as well)
+            L[r] = (int)std::floor(ext + (span ? 1.0e-8 : 0.0)) + 3 + c.halo2;
         }
         if (!ok) continue;
         L[2] = (L[2] + 3 + 3) & ~3;
         const int rows = L[0] * L[1];
-        if (rows > packed_rows_max() || L[2] > 4000) continue;
+        if (rows > (span ? span_rows_max() : packed_rows_max()) || L[2] > 4000 || L[1] > 1023 || L[0] > 511) continue;
         // the kernel stages a box inside the volume through ONE buffer descriptor based at the box origin: the 32-bit byte offset of the
         // box's last row must stay below the descriptor's 2^31 - 1 records (planes of 4096 x 4128 floats reach that at 32 box planes;
-        // plan_block has the same bound)
+        // plan_block has the same bound); the output tile's planes are addressed the same way
         if ((int64_t)L[0] * v->H * v->P * 4 >= 0x7fffffffLL) continue;
+        if (span && (int64_t)(T[0] + 1) * v->oH * v->oW * 4 >= 0x7fffffffLL) continue;
+        // ... and its rim tiles recover a staging vector's (z, y, x) inside the box by dividing its offset by the source's plane and row
+        // sizes: the box must not be larger than the volume in y or x (tiny volumes: the other families serve them)
+        if (span && (L[1] > v->H || L[2] > v->P)) continue;
         for (int i = 0; i < 9; ++i) g.inv[i] = inv[i];
         for (int cc = 0; cc < 3; ++cc) g.cst[cc] = inv[3 * cc] * neg[0] + inv[3 * cc + 1] * neg[1] + inv[3 * cc + 2] * neg[2];
         g.T[0] = T[0]; g.T[1] = T[1]; g.T[2] = T[2];
@@ -764,18 +774,26 @@ void pick_packed_tile(PlanCtx& c, const double inv[9], PackedChoice* out)
             int mn, mx;
             if (packed_row_span(g, row / L[1], row % L[1], &mn, &mx)) nvec += ((mx - (mn & ~3)) >> 2) + 1;
         }
-        const int cap_vec = nvec + rows / 16 + 8;                 // margin for host/device rounding differences
-        if (cap_vec > packed_vectors_max()) continue;
-        const int table_floats = (2 * rows + 8 + 3) & ~3;
-        const int64_t bytes = ((int64_t)table_floats + (int64_t)cap_vec * 4) * 4;
+        int cap_vec = nvec + rows / 16 + 8;                       // margin for host/device rounding differences
+        if (span) cap_vec = (cap_vec + 63) & ~63;                 // whole waves stage
+        if (cap_vec > (span ? span_vectors_max() : packed_vectors_max())) continue;
+        const bool pipe = span && span_config_pipelined(cfg);     // software-pipelined tiles: two footprint buffers
+        if (span && v->tune.span_pipe >= 0 && pipe != (v->tune.span_pipe != 0)) continue;
+        if (pipe && cap_vec > 2560) continue;                      // (its descriptor list is written by 8 x 320 threads)
+        const int table_floats = span ? (pipe ? 4 * rows + 84 : 4 * rows + 8) : (2 * rows + 8 + 3) & ~3;   // (wave-specialised: + four parameter slots)
+        const int64_t bytes = ((int64_t)table_floats + (int64_t)cap_vec * 4 * (pipe ? 2 : 1) + (pipe ? cap_vec : 0)) * 4;   // (wave-specialised: + the descriptor list)
         if (bytes > v->lds_limit) continue;
-        const int blocks_per_cu = (int)std::min<int64_t>(c.cubic ? 2 : 3, (160 * 1024) / bytes);   // VGPR-limited occupancy
+        const int blocks_per_cu = (int)std::min<int64_t>(c.cubic ? 2 : (span ? 4 : 3), (160 * 1024) / bytes);   // VGPR-limited occupancy
         const double vox = (double)T[0] * T[1] * T[2];
-        const double cost = (double)bytes / vox * (blocks_per_cu >= 3 ? 1.0 : (blocks_per_cu == 2 ? 1.2 : 2.0));
+        double cost = (double)bytes / vox * (blocks_per_cu >= 3 ? 1.0 : (blocks_per_cu == 2 ? 1.2 : 2.0));
+        // [measured, 512^3, 24 of the reference's random rotations, per-matrix timings: tools/span_probe.py] the launch time follows the resident
+        // workgroups per CU first (4: 0.34-0.35 ms, 3: 0.37-0.43, 2: 0.46-0.50), then the tile: at equal occupancy 16 x 8 x 32 (two whole
+        // 128-byte output lines per store instruction) takes 0.03 ms less than 16 x 16 x 16, and an 8-deep tile pays the per-tile work twice
+        if (span) cost *= (blocks_per_cu >= 4 ? 0.90 : 1.0) * (T[0] >= 16 ? 1.0 : 1.15) * (T[2] >= 32 ? 0.93 : 1.0);
         if (cost < best) {
             best = cost;
             out->found = true;
-            out->bpv = (double)bytes / vox;
+            out->bpv = (double)(((int64_t)table_floats + (int64_t)cap_vec * 4) * 4) / vox;      // staged bytes per voxel (one buffer)
             out->plan.kind = 6; out->plan.cfg = cfg; out->plan.td = T[0]; out->plan.th = T[1]; out->plan.tw = T[2];
             out->plan.lds_bytes = (int)bytes;
             out->p.Lz = L[0]; out->p.Ly = L[1]; out->p.Lx = cap_vec * 4;
