@@ -195,8 +195,15 @@ def main():
     out = vt.empty((nd, n, n), device=dev)
     gshape = (nd * world, n, n)
     centre = np.divide(np.subtract(gshape, 1), 2, dtype=np.float32)
-    mats = [vt.utils.transform_matrix(rotation=(0, float(i % 180), 0), rotation_units='deg', rotation_order='rzxz',
-                                      center=centre) for i in range(args.warmup + args.steps)]
+    # The timed steps span the README sweep whatever their number: `--steps 180` is `for i in range(180): rotate((0, i, 0))` itself
+    # (README.md:25-27), fewer steps take every (180 / steps)-th angle -- 20 steps are 0, 9, ..., 171 degrees, not 5..24: the per-angle
+    # time varies by +-10 % with the footprint's shape, and a short run must not depend on where it starts.  Warm-up launches use the
+    # first angles of the same list.
+    def sweep_angle(i, count):
+        return float(i % 180) if count >= 180 else float(round(i * 180.0 / count) % 180)
+    timed = [vt.utils.transform_matrix(rotation=(0, sweep_angle(i, args.steps), 0), rotation_units='deg', rotation_order='rzxz', center=centre)
+             for i in range(args.steps)]
+    mats = [timed[i % len(timed)] for i in range(args.warmup)] + timed
 
     def barrier():
         if dist is not None:
@@ -267,7 +274,11 @@ def main():
         'config': {'workload': f'{n}^3 float32 {interp}, StaticVolume resident in HBM, rotate((0,i,0)) rzxz sweep, '
                                f'output= device buffer' + (f', {world} axis-0 slabs of {nd}x{n}x{n}' if world > 1 else ''),
                    'tile': list(info.last_tile), 'lds_bytes': int(info.last_lds_bytes), 'kernel': int(info.last_kernel),
-                   'prefilter_ms_once': round(float(info.prefilter_ms), 3), 'prewarm_ms': round(prewarm_ms, 1)},
+                   'prefilter_ms_once': round(float(info.prefilter_ms), 3), 'prewarm_ms': round(prewarm_ms, 1),
+                   # what the handle built lazily and keeps (the z-convolved plane-quad copies of the orientations the sweep uses, the
+                   # in-plane transposed copy): GPU time of those builds, once per handle, and everything resident now
+                   'zfir_copy_ms_once': round(float(getattr(info, 'copies_ms', 0.0)), 3), 'resident_bytes': int(info.resident_bytes),
+                   'angles': 'i' if args.steps >= 180 else f'round(i * 180 / {args.steps})'},
         'roofline': {'bound': 'hbm', 'kernel': kname, 'achieved': round(achieved, 1), 'peak': 8000.0,
                      'unit': 'GB/s', 'frac': round(achieved / 8000.0, 4),
                      'traffic': (round(traffic['bytes']) if traffic else None),
@@ -278,6 +289,14 @@ def main():
                                       'max': round(float(step_ms.max()), 4), 'mean': round(float(step_ms.mean()), 4),
                                       'method': f'{rep} back-to-back launches of one angle per HIP event pair, after the timed region'}},
     }
+    if world > 1:
+        # a first multi-GPU run should diagnose itself: every rank's own kernel time and halo time, not only the maximum
+        mine = torch.tensor([kernel_ms, float(getattr(sv, 'halo_ms', 0.0))], dtype=torch.float64, device='cuda')
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per = [[float(x) for x in t_.tolist()] for t_ in allr]
+        result['per_rank'] = {'kernel_ms': [round(a[0], 4) for a in per], 'halo_ms': [round(a[1], 3) for a in per],
+                              'kernel_ms_min': round(min(a[0] for a in per), 4), 'kernel_ms_max': round(max(a[0] for a in per), 4)}
     if use_slab:
         # the path's only communication happened once, at construction (halo planes, point to point)
         hm = torch.tensor([float(sv.halo_ms)], dtype=torch.float64, device='cuda')
@@ -327,11 +346,29 @@ def main():
                                         'frac_of_8TBps': round(8.0 * 1024 ** 3 / msb / 1e6 / 8000.0, 4),
                                         'angles': '0..174 step 6 (30 launches)', 'tile': list(svb.info().last_tile), 'kernel': int(svb.info().last_kernel)}
                 svb.close()
+                # BASELINE config #4: the same volume, `filt_bspline`, same 30 angles (its 180-step sweep at a sixth of the launches)
+                svc = vt.StaticVolume(big, interpolation='filt_bspline', device=dev)
+                for m_ in mb:
+                    svc.affine(m_, output=outb)
+                svc.synchronize()
+                svc.timer_start()
+                for m_ in mb:
+                    svc.affine(m_, output=outb)
+                msc = svc.timer_stop() / len(mb)
+                ic = svc.info()
+                extra['filt_bspline_1024'] = {'kernel_ms': round(msc, 4), 'Mvoxels_per_s': round(1024 ** 3 / msc / 1e3, 1),
+                                              'achieved_GBps': round(8.0 * 1024 ** 3 / msc / 1e6, 1),
+                                              'frac_of_8TBps': round(8.0 * 1024 ** 3 / msc / 1e6 / 8000.0, 4),
+                                              'angles': '0..174 step 6 (30 launches)', 'tile': list(ic.last_tile), 'kernel': int(ic.last_kernel),
+                                              'prefilter_ms_once': round(float(ic.prefilter_ms), 3), 'resident_bytes': int(ic.resident_bytes),
+                                              'copies_ms_once': round(float(getattr(ic, 'copies_ms', 0.0)), 3)}
+                svc.close()
                 outb.free()
                 del big
                 torch.cuda.empty_cache()
             except Exception as e:  # pragma: no cover  (e.g. a smaller device)
-                extra['linear_1024'] = {'error': str(e)}
+                extra.setdefault('linear_1024', {'error': str(e)})
+                extra.setdefault('filt_bspline_1024', {'error': str(e)})
         if n == 512:
             # the reference's own benchmark protocol (tests/benchmark.py:52-54): random `sxyz` rotations about size/2 on the resident
             # volume, device output -- the general-matrix kernels (lane blocks for cubic, packed footprints for trilinear)
@@ -383,21 +420,24 @@ def main():
                                   'achieved_GBps': round(24.0 * n ** 3 / pf2 / 1e6, 1), 'frac_of_8TBps': round(24.0 * n ** 3 / pf2 / 1e6 / 8000.0, 4),
                                   'algorithmic_bytes': 24.0 * n ** 3, 'kernels': 'prefilter_xy<16,10> (X+Y fused) + prefilter_block<16,18> (Z)'}
         result['extra'] = extra
-    if rank == 0 and not args.no_cpu_baseline:
-        # "throughput at 1/2/4/8 GPUs reported next to the CPU baseline timed on the same box's host cores" (north star): rank 0 times a
-        # bounded sample of ITS slab's workload while the other ranks wait at the final barrier; the 15 s single-thread scipy pass over
-        # the whole headline volume runs at N = 1 only
-        host_vol = vol if isinstance(vol, np.ndarray) else vol.cpu().numpy()
-        result['cpu_baseline'] = cpu_baseline(host_vol, interp, args.cpu_seconds if world == 1 else min(args.cpu_seconds, 8.0),
-                                              scipy_same_workload=(world == 1))
-
     sv.close()
     out.free()
-    if rank == 0:
-        print(json.dumps(result))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and not args.no_cpu_baseline:
+        # "throughput at 1/2/4/8 GPUs reported next to the CPU baseline timed on the same box's host cores" (north star): rank 0 times a
+        # bounded sample of ITS slab's workload -- after the process group is gone, so that no rank sits in a collective while the host
+        # works, and at N > 1 on a bounded crop of the slab (at most 256 planes cross PCIe and are prefiltered on the host, whatever the
+        # slab's size); the 15 s single-thread scipy pass over the whole headline volume runs at N = 1 only
+        if world > 1 and nd > 256:
+            host_vol = (vol[:256] if isinstance(vol, np.ndarray) else vol[:256].cpu().numpy())
+        else:
+            host_vol = vol if isinstance(vol, np.ndarray) else vol.cpu().numpy()
+        result['cpu_baseline'] = cpu_baseline(np.ascontiguousarray(host_vol), interp, args.cpu_seconds if world == 1 else min(args.cpu_seconds, 8.0),
+                                              scipy_same_workload=(world == 1))
+    if rank == 0:
+        print(json.dumps(result))
 
 
 if __name__ == '__main__':

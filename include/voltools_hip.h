@@ -99,7 +99,11 @@ typedef struct vt_volume_info {
     int32_t last_lds_bytes;
     int32_t last_grid;
     float   prefilter_ms;              /* one-time prefilter time measured at create (filt_*), else 0      */
-    uint64_t resident_bytes;
+    uint64_t resident_bytes;           /* the plain resident copy and every lazily built one the handle holds now */
+    float   copies_ms;                 /* GPU time spent so far building lazy copies (relayouts; hip events on the handle's stream) */
+    int32_t copies_built;              /* lazy copies built so far (rebuilt ones count again) */
+    int32_t copies_evicted;            /* ... and released to stay inside the budget */
+    uint64_t max_resident_bytes;       /* the handle's budget (vt_volume_set_max_resident), 0 = none */
 } vt_volume_info_t;
 
 /* ---- devices: replaces general.py:61-88 (cupy.cuda.runtime.getDeviceCount, Device(i).use()) ---- */
@@ -157,6 +161,11 @@ int vt_has_legacy_kernels(void);
  * rebuilds it; results are unchanged.  freed_bytes may be NULL.  (No reference counterpart: the reference keeps one CUDA array per
  * StaticVolume, volume.py:37-45; cupy's pool serves `free_all_blocks()` for its temporaries.) */
 int vt_volume_release_copies(vt_volume_t* vol, uint64_t* freed_bytes);
+/* Resident-memory budget of the handle in bytes, the plain copy included (0 = none; default: VT_MAX_RESIDENT_GB or none).  Before a lazy
+ * copy is built the least recently used ones are released until it fits; a copy that cannot fit is not built and the call runs on the
+ * kernel family that samples the plain layout.  Results do not depend on the budget.  (No reference counterpart: the reference keeps
+ * exactly one CUDA array per StaticVolume, volume.py:37-45.) */
+int vt_volume_set_max_resident(vt_volume_t* vol, uint64_t bytes);
 int vt_volume_destroy(vt_volume_t* vol);
 int vt_volume_info(const vt_volume_t* vol, vt_volume_info_t* info);
 int vt_volume_stream(const vt_volume_t* vol, void** hip_stream);   /* the hipStream_t launches go to */

@@ -33,6 +33,11 @@ def protocol(n, nrot=100):
         for m in mats:                                # all 100, first call included, as the reference averages them
             vt.affine(data, m, interpolation=interp, device='gpu')
         row['np_transform_ms'] = round((time.perf_counter() - t0) / nrot * 1e3, 4)               # README 'transforms_affine' numpy in/out
+        t0 = time.perf_counter()
+        for m in mats:                                # numpy in, device `output=` (tests/benchmark.py:62): upload + prefilter + kernel per call, no download
+            vt.affine(data, m, interpolation=interp, device='gpu', output=out)
+        sv.synchronize()
+        row['np_transform_out_ms'] = round((time.perf_counter() - t0) / nrot * 1e3, 4)           # README 'transforms_affine_out'
         outs = vt.empty((nrot, n, n, n), device='gpu:0') if n <= 100 else None
         if outs is not None:
             mm = np.stack(mats)

@@ -30,7 +30,7 @@ SYMBOLS = [
     'vt_volume_sync', 'vt_volume_set_output_shape', 'vt_volume_affine', 'vt_volume_affine_f64',
     'vt_volume_project', 'vt_volume_project_f64', 'vt_volume_affine_batch',
     'vt_timer_start', 'vt_timer_stop', 'vt_prefilter_inplace', 'vt_affine_oneshot',
-    'vt_last_error', 'vt_version', 'vt_has_legacy_kernels', 'vt_volume_release_copies',
+    'vt_last_error', 'vt_version', 'vt_has_legacy_kernels', 'vt_volume_release_copies', 'vt_volume_set_max_resident',
 ]
 
 
@@ -41,7 +41,8 @@ class VolumeInfo(ctypes.Structure):
                 ('last_kernel', ctypes.c_int32), ('last_tile', ctypes.c_int32 * 3),
                 ('last_lds_dims', ctypes.c_int32 * 3), ('last_lds_bytes', ctypes.c_int32),
                 ('last_grid', ctypes.c_int32), ('prefilter_ms', ctypes.c_float),
-                ('resident_bytes', ctypes.c_uint64)]
+                ('resident_bytes', ctypes.c_uint64), ('copies_ms', ctypes.c_float), ('copies_built', ctypes.c_int32),
+                ('copies_evicted', ctypes.c_int32), ('max_resident_bytes', ctypes.c_uint64)]
 
 
 _lib = None
@@ -105,6 +106,7 @@ def load():
     L.vt_volume_stream.argtypes = [c_void_p, P(c_void_p)]
     L.vt_volume_sync.argtypes = [c_void_p]
     L.vt_volume_release_copies.argtypes = [c_void_p, P(ctypes.c_uint64)]
+    L.vt_volume_set_max_resident.argtypes = [c_void_p, ctypes.c_uint64]
     L.vt_volume_set_output_shape.argtypes = [c_void_p, c_int, c_int, c_int]
     L.vt_volume_affine.argtypes = [c_void_p, c_void_p, c_void_p, c_int]
     L.vt_volume_affine_f64.argtypes = [c_void_p, c_void_p, c_void_p, c_int]

@@ -365,6 +365,8 @@ struct Orientation {
     float** quad_slot = nullptr;       // where its plane-quad form lives
     float** quade_slot = nullptr;      // ... and the plane-quad form of its z-convolved volume (cubic launches with an integer axis-0 offset)
     int quad_idx = 0;
+    int plain_id = -1;                 // LazyCopyId of the exchanged plain-layout copy this orientation is based on (-1: the handle's own plain copy);
+                                       // built by ensure_secondary_copy only when the launch -- or the relayout of a missing quad form -- reads it
     int srcD = 0, srcH = 0;            // depth / height of that copy
     int rowW = 0, rowP = 0;            // row width / pitch of that copy
     bool xswap = false;                // the kernels write an axis-0 <-> 2 exchanged result into d_tmp_x
@@ -396,6 +398,188 @@ vt_volume planning_view(const vt_volume* v, int D, int H, int W, int P, int oD, 
     return sw;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// lazily built resident copies: one place that allocates, times, budgets and evicts them
+// ---------------------------------------------------------------------------------------------------
+// A handle that has used every orientation holds up to 13 buffers besides its plain copy.  Round 5: they are built
+// through alloc_lazy(), which (1) keeps the handle inside its budget (vt_volume_set_max_resident / VT_MAX_RESIDENT_GB; the plain copy
+// counts) by releasing the least recently used copies first, (2) does the same once when hipMalloc fails without any budget -- a device
+// short of memory then trades an old orientation's copies for the new one instead of falling back to the slower family for good --, and
+// (3) never builds a copy that cannot fit the budget at all: the caller falls back to the family that reads the plain layout.
+enum LazyCopyId { kCopyT = 0, kCopyR, kCopyX, kCopyXe, kCopyQ0, kCopyQ1, kCopyQ2, kCopyQ3, kCopyQe0, kCopyQe1, kCopyQe2, kCopyQe3, kCopyTmpX, kCopyCount };
+
+float** lazy_slot(vt_volume* v, int id)
+{
+    switch (id) {
+        case kCopyT: return &v->d_src_t;
+        case kCopyR: return &v->d_src_r;
+        case kCopyX: return &v->d_src_x;
+        case kCopyXe: return &v->d_src_xe;
+        case kCopyQ0: return &v->d_src_q;
+        case kCopyQ1: return &v->d_src_t_q;
+        case kCopyQ2: return &v->d_src_r_q;
+        case kCopyQ3: return &v->d_src_x_q;
+        case kCopyQe0: case kCopyQe1: case kCopyQe2: case kCopyQe3: return &v->d_src_qe[id - kCopyQe0];
+        default: return &v->d_tmp_x;
+    }
+}
+
+uint64_t lazy_bytes(const vt_volume* v, int id)
+{
+    const uint64_t plain = (uint64_t)v->D * v->H * v->P * sizeof(float);
+    switch (id) {
+        case kCopyT: return v->d_src_t ? plain : 0;
+        case kCopyR: return v->d_src_r ? (uint64_t)v->D * v->W * v->Pr * sizeof(float) : 0;
+        case kCopyX: return v->d_src_x ? (uint64_t)v->W * v->H * v->Px * sizeof(float) : 0;
+        case kCopyXe: return v->d_src_xe ? plain : 0;
+        case kCopyQ0: case kCopyQ1: case kCopyQ2: case kCopyQ3: return v->quad_bytes[id - kCopyQ0];
+        case kCopyQe0: case kCopyQe1: case kCopyQe2: case kCopyQe3: return v->quade_bytes[id - kCopyQe0];
+        default: return v->d_tmp_x ? (uint64_t)v->tmp_x_elems * sizeof(float) : 0;
+    }
+}
+
+uint64_t resident_now(const vt_volume* v)
+{
+    uint64_t tot = (uint64_t)v->D * v->H * v->P * sizeof(float) + (v->proj ? (uint64_t)3 * v->proj->H * v->proj->P * sizeof(float) : 0);
+    for (int id = 0; id < kCopyCount; ++id) tot += lazy_bytes(v, id);
+    return tot + v->spare_bytes;
+}
+
+void drop_spare(vt_volume* v)
+{
+    if (v->spare) { (void)hipFree(v->spare); (void)hipGetLastError(); }
+    v->spare = nullptr; v->spare_bytes = 0;
+}
+
+void touch_lazy(vt_volume* v, int id) { if (id >= 0 && id < kCopyCount) v->copy_used[id] = v->use_clock; }
+
+// release the least recently used lazy copy that is none of keep_a / keep_b; false when there is none
+bool evict_lru(vt_volume* v, int keep_a, int keep_b)
+{
+    int victim = -1;
+    for (int id = 0; id < kCopyCount; ++id) {
+        if (id == keep_a || id == keep_b || !*lazy_slot(v, id)) continue;
+        if (victim < 0 || v->copy_used[id] < v->copy_used[victim]) victim = id;
+    }
+    if (victim < 0) return false;
+    (void)hipStreamSynchronize(v->stream);                        // no launch may still be reading what is released
+    float** s = lazy_slot(v, victim);
+    const size_t vbytes = (size_t)lazy_bytes(v, victim);
+    drop_spare(v);
+    v->spare = *s; v->spare_bytes = vbytes;                       // kept for the next build of that size (alloc_lazy); counted as resident
+    *s = nullptr;
+    if (victim >= kCopyQ0 && victim <= kCopyQ3) v->quad_bytes[victim - kCopyQ0] = 0;
+    if (victim >= kCopyQe0 && victim <= kCopyQe3) v->quade_bytes[victim - kCopyQe0] = 0;
+    if (victim == kCopyTmpX) v->tmp_x_elems = 0;
+    v->copies_evicted += 1;
+    if (std::getenv("VT_DEBUG_ALLOC")) std::fprintf(stderr, "[vt] evicted lazy copy %d (last used at launch %llu of %llu)\n", victim,
+                                                    (unsigned long long)v->copy_used[victim], (unsigned long long)v->use_clock);
+    return true;
+}
+
+// Allocate lazy copy `id` (`bytes` large) into its slot; keep_a / keep_b: copies this build reads or the launch needs.  hipSuccess, or
+// hipErrorOutOfMemory when the budget or the device cannot hold it (nothing is left half-built).
+// `transient`: a copy that only this build reads (the exchanged plain copy a plane-quad form is made from) and that is released right after
+// the build where the budget asks for it: it does not count against the budget while the build runs -- the budget bounds what a handle
+// KEEPS; for the few milliseconds of a relayout the handle may hold that source beside it (release_transient).
+hipError_t alloc_lazy(vt_volume* v, int id, size_t bytes, int keep_a, int keep_b, int transient = -1)
+{
+    float** slot = lazy_slot(v, id);
+    auto spare_fits = [&]() { return v->spare && v->spare_bytes >= bytes && v->spare_bytes - bytes <= bytes / 8; };
+    if (v->max_resident) {
+        const uint64_t leaving = transient >= 0 ? lazy_bytes(v, transient) : 0;
+        for (;;) {
+            const uint64_t held = resident_now(v) - leaving - (spare_fits() ? v->spare_bytes : 0);
+            if (held + bytes <= v->max_resident) break;
+            if (v->spare && !spare_fits()) { drop_spare(v); continue; }
+            if (!evict_lru(v, id == keep_a ? -1 : keep_a, keep_b)) return hipErrorOutOfMemory;        // does not fit the budget at all
+        }
+    }
+    if (spare_fits()) {
+        *slot = v->spare;
+        v->spare = nullptr; v->spare_bytes = 0;
+        touch_lazy(v, id);
+        return hipSuccess;
+    }
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(slot), bytes);
+    while (e != hipSuccess) {
+        (void)hipGetLastError();
+        *slot = nullptr;
+        if (v->spare) drop_spare(v);
+        else if (!evict_lru(v, keep_a, keep_b)) return hipErrorOutOfMemory;
+        e = hipMalloc(reinterpret_cast<void**>(slot), bytes);
+    }
+    touch_lazy(v, id);
+    return hipSuccess;
+}
+
+// after a build that read `transient`: back inside the budget, the build's source first
+void release_transient(vt_volume* v, int transient, int keep)
+{
+    if (!v->max_resident || resident_now(v) <= v->max_resident) return;
+    if (transient >= 0 && *lazy_slot(v, transient)) {
+        for (int id = 0; id < kCopyCount; ++id) if (id != transient && *lazy_slot(v, id) && v->copy_used[id] == 0) v->copy_used[id] = 1;
+        const uint64_t stamp = v->copy_used[transient];
+        v->copy_used[transient] = 0;                                  // the least recently used one by decree
+        if (!evict_lru(v, keep, -1)) v->copy_used[transient] = stamp;
+    }
+    while (resident_now(v) > v->max_resident) {
+        if (v->spare) { drop_spare(v); continue; }
+        if (!evict_lru(v, keep, -1)) break;
+    }
+}
+
+// GPU time of a copy's build, for vt_volume_info.copies_ms (events of their own: the handle's timer may be running)
+void lazy_build_begin(vt_volume* v)
+{
+    if (!v->evc0) { (void)hipEventCreate(&v->evc0); (void)hipEventCreate(&v->evc1); }
+    if (v->evc0) (void)hipEventRecord(v->evc0, v->stream);
+}
+void lazy_build_end(vt_volume* v)
+{
+    v->copies_built += 1;
+    if (!v->evc0 || !v->evc1) return;
+    float ms = 0.f;
+    if (hipEventRecord(v->evc1, v->stream) == hipSuccess && hipEventSynchronize(v->evc1) == hipSuccess &&
+        hipEventElapsedTime(&ms, v->evc0, v->evc1) == hipSuccess) v->copies_ms += ms;
+    (void)hipGetLastError();
+}
+
+// The exchanged plain-layout copy of an orientation (kCopyT / kCopyR / kCopyX): 0 = it exists, 1 = it cannot be built.
+int ensure_lazy_plain(vt_volume* v, int id)
+{
+    float** slot = lazy_slot(v, id);
+    if (*slot) { touch_lazy(v, id); return 0; }
+    size_t bytes = 0;
+    if (id == kCopyT) bytes = (size_t)v->D * v->H * v->P * sizeof(float);
+    else if (id == kCopyR) { v->Pr = resident_pitch(v->H); bytes = (size_t)v->D * v->W * v->Pr * sizeof(float); }
+    else if (id == kCopyX) { v->Px = resident_pitch(v->D); bytes = (size_t)v->W * v->H * v->Px * sizeof(float); }
+    else return 1;
+    if (alloc_lazy(v, id, bytes, id, -1) != hipSuccess) { *slot = nullptr; return 1; }
+    lazy_build_begin(v);
+    hipError_t e = hipSuccess;
+    if (id == kCopyT) {
+        e = launch_relayout_swap01(v->d_src, v->d_src_t, v->D, v->H, v->P, v->stream);
+    } else {
+        e = hipMemsetAsync(*slot, 0, bytes, v->stream);                                   // pad columns must be zero
+        if (e == hipSuccess && id == kCopyR)        // dst[z][x][y]: element (i = y, j = z, k = x) -> (k = x, j = z, i = y)
+            e = launch_transpose02(v->d_src, v->d_src_r, v->H, v->D, v->W, v->P, (int64_t)v->H * v->P, v->Pr, (int64_t)v->W * v->Pr, v->stream);
+        else if (e == hipSuccess)
+            e = launch_transpose02(v->d_src, v->d_src_x, v->D, v->H, v->W, (int64_t)v->H * v->P, v->P, (int64_t)v->H * v->Px, v->Px, v->stream);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(v->stream);
+        (void)hipFree(*slot);
+        (void)hipGetLastError();
+        *slot = nullptr;
+        return 1;
+    }
+    lazy_build_end(v);
+    return 0;
+}
+
 // Rotations about axis 1 ([a 0 b; 0 1 0; c 0 d]): the same problem with axes 0 and 1 exchanged is axis-0-separable.
 // A second resident copy with those axes exchanged (built once, lazily) lets the marching kernels serve it; only
 // the output addressing changes (plane stride oW, row stride oH*oW).  Whole-volume handles only (no slab offsets).
@@ -419,19 +603,10 @@ int try_axis1_exchange(vt_volume* v, const double m[12], int flags, size_t n_out
     TilePlan plans;
     plan_launch(&sw, ms, flags, &ps, &plans);
     if (!is_marching(plans.kind)) return 0;
-    if (!v->d_src_t) {
-        const size_t bytes = (size_t)v->D * v->H * v->P * sizeof(float);
-        if (hipMalloc(reinterpret_cast<void**>(&v->d_src_t), bytes) != hipSuccess) {
-            (void)hipGetLastError();          // no room for a second copy: the general kernels serve this matrix
-            v->d_src_t = nullptr;
-            return 0;
-        }
-        VT_HIP(launch_relayout_swap01(v->d_src, v->d_src_t, v->D, v->H, v->P, v->stream));
-    }
     *p = ps; *plan = plans;
     p->ostride = v->oW; p->orow = (int64_t)v->oH * v->oW;
     p->ord[0] = 1; p->ord[1] = 0; p->ord[2] = 2;          // original (d, h, w) = this launch's columns (1, 0, 2)
-    ori->src_plain = v->d_src_t; ori->quad_slot = &v->d_src_t_q; ori->quade_slot = &v->d_src_qe[1]; ori->quad_idx = 1;
+    ori->src_plain = v->d_src_t; ori->plain_id = kCopyT; ori->quad_slot = &v->d_src_t_q; ori->quade_slot = &v->d_src_qe[1]; ori->quad_idx = 1;
 #ifdef VT_LEGACY
     ori->pair_slot = &v->d_src_t_zp;
 #endif
@@ -464,30 +639,10 @@ int try_axis2_exchange(vt_volume* v, const double m[12], int flags, size_t n_out
     TilePlan plans;
     plan_launch(&sw, ms, flags, &ps, &plans);
     if (!is_marching(plans.kind)) return 0;
-    if (v->tmp_x_elems < n_out) {
-        if (v->d_tmp_x) { VT_HIP(hipFree(v->d_tmp_x)); v->d_tmp_x = nullptr; v->tmp_x_elems = 0; }
-        if (hipMalloc(reinterpret_cast<void**>(&v->d_tmp_x), n_out * sizeof(float)) != hipSuccess) {
-            (void)hipGetLastError();          // no room: the general kernels serve this matrix
-            v->d_tmp_x = nullptr;
-            return 0;
-        }
-        v->tmp_x_elems = n_out;
-    }
-    if (!v->d_src_x) {
-        v->Px = sw.P;
-        const size_t bytes = (size_t)v->W * v->H * v->Px * sizeof(float);
-        if (hipMalloc(reinterpret_cast<void**>(&v->d_src_x), bytes) != hipSuccess) {
-            (void)hipGetLastError();
-            v->d_src_x = nullptr;
-            return 0;
-        }
-        VT_HIP(hipMemsetAsync(v->d_src_x, 0, bytes, v->stream));          // pad columns must be zero
-        VT_HIP(launch_transpose02(v->d_src, v->d_src_x, v->D, v->H, v->W, (int64_t)v->H * v->P, v->P,
-                                  (int64_t)v->H * v->Px, v->Px, v->stream));
-    }
+    v->Px = sw.P;
     *p = ps; *plan = plans;
     p->ord[0] = 2; p->ord[1] = 1; p->ord[2] = 0;          // original (d, h, w) = this launch's columns (2, 1, 0)
-    ori->src_plain = v->d_src_x; ori->quad_slot = &v->d_src_x_q; ori->quade_slot = &v->d_src_qe[3]; ori->quad_idx = 3;
+    ori->src_plain = v->d_src_x; ori->plain_id = kCopyX; ori->quad_slot = &v->d_src_x_q; ori->quade_slot = &v->d_src_qe[3]; ori->quad_idx = 3;
 #ifdef VT_LEGACY
     ori->pair_slot = &v->d_src_x_zp;
 #endif
@@ -515,21 +670,9 @@ int try_inplane_transposed(vt_volume* v, const double m[12], int flags, size_t n
     TilePlan plans;
     plan_launch(&sw, ms, flags, &ps, &plans);
     if (!is_marching(plans.kind)) return 0;
-    if (!v->d_src_r) {
-        v->Pr = sw.P;
-        const size_t bytes = (size_t)v->D * v->W * v->Pr * sizeof(float);
-        if (hipMalloc(reinterpret_cast<void**>(&v->d_src_r), bytes) != hipSuccess) {
-            (void)hipGetLastError();          // no room for another copy: the plain layout serves this matrix
-            v->d_src_r = nullptr;
-            return 0;
-        }
-        VT_HIP(hipMemsetAsync(v->d_src_r, 0, bytes, v->stream));          // pad columns must be zero
-        // dst[x][z][y] in (k, j, i) terms: element (i = y, j = z, k = x) -> (k = x, j = z, i = y)
-        VT_HIP(launch_transpose02(v->d_src, v->d_src_r, v->H, v->D, v->W, v->P, (int64_t)v->H * v->P,
-                                  v->Pr, (int64_t)v->W * v->Pr, v->stream));
-    }
+    v->Pr = sw.P;
     *p = ps; *plan = plans;
-    ori->src_plain = v->d_src_r; ori->quad_slot = &v->d_src_r_q; ori->quade_slot = &v->d_src_qe[2]; ori->quad_idx = 2;
+    ori->src_plain = v->d_src_r; ori->plain_id = kCopyR; ori->quad_slot = &v->d_src_r_q; ori->quade_slot = &v->d_src_qe[2]; ori->quad_idx = 2;
 #ifdef VT_LEGACY
     ori->pair_slot = &v->d_src_r_zp;
 #endif
@@ -577,25 +720,13 @@ int try_general_reorient(vt_volume* v, const double m[12], int flags, size_t n_o
     TilePlan plans;
     plan_launch(&sw, ms, flags, &ps, &plans);
     if (!(plans.kind == 2 || plans.kind == 6 || plans.kind == 9)) return 0;           // the general-matrix kernels only
-    if (!*slot) {
-        const size_t bytes = (size_t)sw.D * sw.H * sw.P * sizeof(float);
-        if (hipMalloc(reinterpret_cast<void**>(slot), bytes) != hipSuccess) {
-            (void)hipGetLastError();          // no room for another copy: the plain layout serves this matrix
-            *slot = nullptr;
-            *asked = -64;                     // ... and the next 64 requests
-            return 0;
-        }
-        VT_HIP(hipMemsetAsync(*slot, 0, bytes, v->stream));                              // pad columns must be zero
-        if (a == 1) {
-            v->Pr = sw.P;
-            VT_HIP(launch_transpose02(v->d_src, v->d_src_r, v->H, v->D, v->W, v->P, (int64_t)v->H * v->P, v->Pr, (int64_t)v->W * v->Pr, v->stream));
-        } else {
-            v->Px = sw.P;
-            VT_HIP(launch_transpose02(v->d_src, v->d_src_x, v->D, v->H, v->W, (int64_t)v->H * v->P, v->P, (int64_t)v->H * v->Px, v->Px, v->stream));
-        }
+    if (a == 1) v->Pr = sw.P; else v->Px = sw.P;
+    if (ensure_lazy_plain(v, a == 1 ? kCopyR : kCopyX)) {
+        *asked = -64;                         // no room for another copy: the plain layout serves this matrix and the next 64 requests
+        return 0;
     }
     *p = ps; *plan = plans;
-    ori->src_plain = *slot;
+    ori->src_plain = *slot; ori->plain_id = a == 1 ? kCopyR : kCopyX;
     ori->srcD = sw.D; ori->srcH = sw.H; ori->rowW = sw.W; ori->rowP = sw.P;
     return 0;
 }
@@ -612,12 +743,12 @@ int try_rows(vt_volume* v, const double m[12], int flags, AffineParams* p, TileP
     if (is_cubic(v->interp) && !v->d_src_xe) {
         if (v->xe_retry_in > 0) { --v->xe_retry_in; return 0; }
         const size_t bytes = (size_t)v->D * v->H * v->P * sizeof(float);
-        if (hipMalloc(reinterpret_cast<void**>(&v->d_src_xe), bytes) != hipSuccess) {
-            (void)hipGetLastError();          // no room for the copy: the exchange path or the general kernels serve this matrix
-            v->d_src_xe = nullptr;
+        if (alloc_lazy(v, kCopyXe, bytes, kCopyXe, -1) != hipSuccess) {
+            v->d_src_xe = nullptr;            // no room for the copy: the exchange path or the general kernels serve this matrix
             v->xe_retry_in = 64;
             return 0;
         }
+        lazy_build_begin(v);
         const bool simple = v->interp == VT_BSPLINE_SIMPLE || v->interp == VT_FILT_BSPLINE_SIMPLE;
         if (launch_relayout_xfir(v->d_src, v->d_src_xe, v->D, v->H, v->W, v->P, simple, v->stream) != hipSuccess) {
             (void)hipGetLastError();
@@ -627,8 +758,10 @@ int try_rows(vt_volume* v, const double m[12], int flags, AffineParams* p, TileP
             v->xe_retry_in = 64;
             return 0;
         }
+        lazy_build_end(v);
     }
     *p = ps; *plan = plans;
+    if (is_cubic(v->interp)) touch_lazy(v, kCopyXe);
     ori->src_plain = is_cubic(v->interp) ? v->d_src_xe : v->d_src;
     return 0;
 }
@@ -646,21 +779,41 @@ void note_launch(vt_volume* v, int kind, const TilePlan& plan, const AffineParam
 // Build the secondary resident copy a plan needs (once per handle and orientation).  Returns 0 when the copy exists, 1 when it
 // could not be built -- no device memory for it, or a relayout launch that was refused: the slot is freed and cleared (a zero-filled
 // copy must never survive: later calls would sample it silently) and the caller re-plans without this kernel family --, < 0 never.
-int ensure_secondary_copy(vt_volume* v, const TilePlan& plan, const AffineParams& p, const Orientation& ori)
+int ensure_secondary_copy(vt_volume* v, const TilePlan& plan, const AffineParams& p, Orientation& ori)
 {
     float** slot = nullptr;
     size_t bytes = 0;
+    int id = -1;
     const bool zfir = plan.kind == 8 && (p.flags & (1 << 19)) != 0;       // the z-convolved copy (vt_plan.hip: plan_quad)
     if (plan.kind == 8) {
         slot = zfir ? ori.quade_slot : ori.quad_slot;
+        id = (zfir ? kCopyQe0 : kCopyQ0) + ori.quad_idx;
         bytes = (size_t)((ori.srcD + 3) / 4) * ori.srcH * p.sPq * sizeof(float);
 #ifdef VT_LEGACY
     } else if (plan.kind == 5) {
         slot = ori.pair_slot;
         bytes = (size_t)((ori.srcD + 1) / 2) * ori.srcH * p.sP2 * sizeof(float);
 #endif
-    } else return 0;
-    if (*slot) return 0;
+    }
+    // the exchanged result buffer of the axis-0 <-> 2 orientation
+    if (ori.xswap) {
+        const size_t n_out = (size_t)v->oD * v->oH * v->oW;
+        if (v->tmp_x_elems < n_out) {
+            if (v->d_tmp_x) { (void)hipStreamSynchronize(v->stream); (void)hipFree(v->d_tmp_x); v->d_tmp_x = nullptr; v->tmp_x_elems = 0; }
+            if (alloc_lazy(v, kCopyTmpX, n_out * sizeof(float), kCopyTmpX, id) != hipSuccess) { v->d_tmp_x = nullptr; return 1; }
+            v->tmp_x_elems = n_out;
+        }
+        touch_lazy(v, kCopyTmpX);
+    }
+    if (slot && *slot) { touch_lazy(v, id); return 0; }                    // the launch reads this form only: its plain-layout source may be gone
+    // The exchanged plain-layout copy of the orientation: read by the launch itself (kinds that sample the plain layout) or by the relayout
+    // that builds the missing plane-quad form.  Built here and not when the orientation is chosen: under a budget it is the first copy
+    // evicted once its quad form exists, and a sweep must not rebuild it on every call.
+    if (ori.plain_id >= 0) {
+        if (ensure_lazy_plain(v, ori.plain_id)) return 1;
+        ori.src_plain = *lazy_slot(v, ori.plain_id);
+    }
+    if (!slot) return 0;
 #ifdef VT_LEGACY
     if (v->tune.test_fail_copy) return 1;      // VT_TEST_FAIL_COPY (test build): the allocation-failure path, for tests/test_gpu_parity.py
 #endif
@@ -669,13 +822,17 @@ int ensure_secondary_copy(vt_volume* v, const TilePlan& plan, const AffineParams
     constexpr int kCopyRetryCalls = 64;
     int* const retry = (plan.kind == 8) ? &v->copy_retry_in[ori.quad_idx + (zfir ? 4 : 0)] : nullptr;
     if (retry && *retry > 0) { --*retry; return 1; }
-    if (hipMalloc(reinterpret_cast<void**>(slot), bytes) != hipSuccess) {
+    hipError_t e = hipSuccess;
+    if (id >= 0) e = alloc_lazy(v, id, bytes, id, ori.plain_id, ori.plain_id);
+    else e = hipMalloc(reinterpret_cast<void**>(slot), bytes);
+    if (e != hipSuccess) {
         (void)hipGetLastError();              // no room for another copy of the volume: a family that reads the plain layout serves the call
         *slot = nullptr;
         if (retry) *retry = kCopyRetryCalls;
         return 1;
     }
-    hipError_t e = hipMemsetAsync(*slot, 0, bytes, v->stream);       // positions beyond the row's width stay zero
+    lazy_build_begin(v);
+    e = hipMemsetAsync(*slot, 0, bytes, v->stream);       // positions beyond the row's width stay zero
     if (e == hipSuccess) {
         if (zfir)
             e = launch_relayout_zquad_fir(ori.src_plain, *slot, ori.srcD, ori.srcH, ori.rowW, ori.rowP, p.sPq, (p.flags & (1 << 18)) != 0, v->stream);
@@ -695,6 +852,10 @@ int ensure_secondary_copy(vt_volume* v, const TilePlan& plan, const AffineParams
         if (retry) *retry = kCopyRetryCalls;
         return 1;
     }
+    lazy_build_end(v);
+    if (zfir) v->quade_bytes[ori.quad_idx] = bytes;
+    else if (plan.kind == 8) v->quad_bytes[ori.quad_idx] = bytes;
+    if (id >= 0) release_transient(v, ori.plain_id, id);             // (lazy_build_end has waited for the relayout: its source may go)
     if (std::getenv("VT_DEBUG_ALLOC")) std::fprintf(stderr, "[vt] secondary copy kind %d orientation %d at %p, %zu bytes (plain source %p)\n", plan.kind, ori.quad_idx, (void*)*slot, bytes, (const void*)ori.src_plain);
     if (zfir) v->quade_bytes[ori.quad_idx] = bytes;
     else if (plan.kind == 8) v->quad_bytes[ori.quad_idx] = bytes;
@@ -784,6 +945,7 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
     TilePlan plan;
     Orientation ori;
     const size_t n_out = (size_t)v->oD * v->oH * v->oW;
+    v->use_clock += 1;
     // Plan, then make sure the resident copy the plan reads exists.  A copy that cannot be built (device memory: a handle that has
     // used every orientation holds up to 8 copies of its volume) takes its kernel family out of the running and the call is
     // planned again: quad -> pair (cubic) / plain marching -> ... every family from kind 4 down reads the plain layout.
@@ -809,8 +971,11 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
         const int miss = ensure_secondary_copy(v, plan, p, ori);
         if (miss == 0) break;
         if (attempt >= 3) return fail(VT_EINVAL, "no kernel family can serve this call (secondary resident copies cannot be built)");
-        // (the z-convolved copy of KIND 4 missing: the four-plane kernel on the plain plane-quad copy is next in line)
-        deny |= (plan.kind == 8) ? (((p.flags & (1 << 19)) && !(deny & VT_NO_ZFIR)) ? VT_NO_ZFIR : VT_NO_QUAD) : VT_NO_ZPAIR;
+        // (the z-convolved copy of KIND 4 missing: the four-plane kernel on the plain plane-quad copy is next in line; a general-matrix
+        //  launch whose axis-permuted plain copy could not be built samples the plain copy)
+        if (plan.kind == 8) deny |= ((p.flags & (1 << 19)) && !(deny & VT_NO_ZFIR)) ? VT_NO_ZFIR : VT_NO_QUAD;
+        else if (plan.kind == 2 || plan.kind == 6 || plan.kind == 9) deny |= VT_NO_REORIENT;
+        else deny |= VT_NO_ZPAIR;
     }
 
     float* d_out = out;
@@ -905,6 +1070,7 @@ int create_common(int dev, int D, int H, int W, int interp, const float* data, i
     v->plane0 = plane0; v->gD = gD; v->out_plane0 = out_plane0;
     v->edge_pad = pad;
     v->tune.read();
+    if (v->tune.max_resident_gb > 0.0) v->max_resident = (uint64_t)(v->tune.max_resident_gb * 1073741824.0);
 
     auto cleanup = [&](int code) {
         vt_volume_destroy(v);
@@ -1560,12 +1726,15 @@ int vt_volume_destroy(vt_volume_t* v)
     for (int i = 0; i < 4; ++i) if (v->d_src_qe[i]) hipFree(v->d_src_qe[i]);
     if (v->d_src_xe) hipFree(v->d_src_xe);
     if (v->d_tmp_x) hipFree(v->d_tmp_x);
+    if (v->spare) hipFree(v->spare);
     if (v->d_scratch_out) cached_free(v->dev, v->d_scratch_out, v->scratch_elems * sizeof(float));
     if (v->d_proj_tmp) hipFree(v->d_proj_tmp);
     if (v->d_batch_m) hipFree(v->d_batch_m);
     if (v->proj) { vt_volume_destroy(v->proj); v->proj = nullptr; }
     if (v->ev0) recycle_event(v->dev, v->ev0);
     if (v->ev1) recycle_event(v->dev, v->ev1);
+    if (v->evc0) (void)hipEventDestroy(v->evc0);
+    if (v->evc1) (void)hipEventDestroy(v->evc1);
     if (v->stream && v->owns_stream) recycle_stream(v->dev, v->stream);
     delete v;
     return 0;
@@ -1589,6 +1758,7 @@ int vt_volume_release_copies(vt_volume_t* v, uint64_t* freed_bytes)
     };
     for (float** s : slots)
         if (*s) { VT_HIP(hipFree(*s)); *s = nullptr; }
+    drop_spare(v);
     v->tmp_x_elems = 0;
     for (int i = 0; i < 4; ++i) { v->quad_bytes[i] = 0; v->quade_bytes[i] = 0; }
     for (int i = 0; i < 8; ++i) v->copy_retry_in[i] = 0;      // memory was just returned: a copy that did not fit may fit now
@@ -1632,6 +1802,31 @@ int vt_volume_info(const vt_volume_t* v, vt_volume_info_t* info)
                             (v->d_src_r_zp ? (uint64_t)((v->D + 1) / 2) * v->W * v->P2 * sizeof(float) : 0) +
                             (v->d_src_x_zp ? (uint64_t)((v->W + 1) / 2) * v->H * v->P2 * sizeof(float) : 0);
 #endif
+    info->copies_ms = v->copies_ms;
+    info->copies_built = v->copies_built;
+    info->copies_evicted = v->copies_evicted;
+    info->max_resident_bytes = v->max_resident;
+    return 0;
+}
+
+// Resident-memory budget of a handle (round 5; no reference counterpart: the reference keeps one CUDA array per StaticVolume,
+// volume.py:37-45).  `bytes` counts the plain resident copy and every lazily built one; 0 = no limit (the default unless
+// VT_MAX_RESIDENT_GB is set).  A copy that would take the handle over its budget is built only after the least recently used lazy copies
+// have been released; one that cannot fit at all is not built, and the call runs on the kernel family that samples the plain layout.
+// A budget below the handle's present footprint releases copies at once.  Results never depend on the budget.
+int vt_volume_set_max_resident(vt_volume_t* v, uint64_t bytes)
+{
+    if (!v) return fail(VT_EINVAL, "NULL argument");
+    int rc = use_device(v->dev);
+    if (rc) return rc;
+    v->max_resident = bytes;
+    if (bytes)
+        while (resident_now(v) > bytes) {
+            if (v->spare) { drop_spare(v); continue; }
+            if (!evict_lru(v, -1, -1)) break;         // (the plain copy alone may exceed a tiny budget: it stays)
+        }
+    for (int i = 0; i < 8; ++i) v->copy_retry_in[i] = 0;
+    v->xe_retry_in = 0;
     return 0;
 }
 

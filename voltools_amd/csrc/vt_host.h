@@ -46,6 +46,7 @@ struct Tuning {
     bool block_no_trim = false;    // VT_BLOCK_NO_TRIM: the lane-block kernel stages whole boxes (A/B of the footprint trimming)
     int block_min = 240;           // VT_BLOCK_MIN: smallest output (cube edge) that general cubic launches take to the lane-block kernel
     int block_pad = -1;            // VT_BLOCK_PAD: plane-stride padding in floats instead of the bank model's choice
+    double max_resident_gb = 0.0;  // VT_MAX_RESIDENT_GB: default resident-memory budget of every handle in GiB (0 = none); see vt_volume_set_max_resident
     int span = 1;                  // VT_SPAN=0: trilinear general matrices on round 1's packed-footprint kernel (vt_kernels_packed.hip) instead of round 5's (A/B)
     int span_pipe = 0;             // VT_SPAN_PIPE: 1 / 0 = trilinear general matrices on the software-pipelined / the single-buffer form of the packed-span kernel, -1 = the planner's cost model
     int block_th = 8;              // VT_BLOCK_TH: tile height of the lane-block kernel: 8 (8 x 8 x 16 tiles, four workgroups per CU; boxes beyond 40 KiB fall back to 16) or 16 (8 x 16 x 16, two per CU)
@@ -96,6 +97,7 @@ struct Tuning {
         block_th = num("VT_BLOCK_TH", 8) == 16 ? 16 : 8;
         span_pipe = num("VT_SPAN_PIPE", 0);
         span = num("VT_SPAN", 1);
+        { const char* e = std::getenv("VT_MAX_RESIDENT_GB"); max_resident_gb = e ? std::atof(e) : 0.0; }
         block_min = std::max(1, num("VT_BLOCK_MIN", 240));
         block_no_trim = std::getenv("VT_BLOCK_NO_TRIM") != nullptr;
     }
@@ -141,6 +143,15 @@ struct vt_volume {
     float* d_src_x_zp = nullptr;
     int P2 = 0;                        // floats per pair-row of d_src_zp
 #endif
+    // lazily built resident copies: budget, least-recently-used eviction, build time (vt_api.hip: lazy copies)
+    uint64_t max_resident = 0;         // bytes this handle may keep resident, plain copy included (0 = no limit); vt_volume_set_max_resident / VT_MAX_RESIDENT_GB
+    uint64_t use_clock = 0;            // launches so far
+    uint64_t copy_used[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // launch that last read copy i (LazyCopyId)
+    float copies_ms = 0.f;             // GPU time spent building lazy copies so far
+    int copies_built = 0, copies_evicted = 0;
+    hipEvent_t evc0 = nullptr, evc1 = nullptr;
+    float* spare = nullptr;            // the buffer of the lazy copy evicted last, kept for the next build of that size (a sweep under a budget
+    size_t spare_bytes = 0;            // trades one orientation's copy for another's: no hipFree + hipMalloc of gigabytes per switch)
     int* d_queue = nullptr;            // lane-block kernel: tile counters (one per XCD + a departure count), zero between launches
     float* d_scratch_out = nullptr;    // staging for host outputs
     double* d_batch_m = nullptr;       // batch launches: n x 12 folded matrices

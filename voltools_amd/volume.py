@@ -21,9 +21,13 @@ Vec3 = Union[Tuple[float, float, float], np.ndarray]
 class StaticVolume:
     """For StaticVolume transforms the boolean reshape cannot be given as an argument."""
 
-    def __init__(self, data, interpolation: str = 'linear', device: str = 'gpu', *, edge: str = 'texture'):
+    def __init__(self, data, interpolation: str = 'linear', device: str = 'gpu', *, edge: str = 'texture', max_resident_bytes: int = 0):
         """``edge`` (extension, GPU devices): ``'texture'`` = the reference GPU path's boundary contract, ``'scipy'`` = the
-        contract of its CPU path (see ``transforms.py`` of this package)."""
+        contract of its CPU path (see ``transforms.py`` of this package).  ``max_resident_bytes`` (extension, GPU devices): how much HBM
+        this volume may keep resident, its plain copy included -- the copies built lazily per orientation used (``info().resident_bytes``)
+        are released least recently used first to stay inside it, and a copy that cannot fit is not built (the call then runs on the
+        kernels that sample the plain layout; results are the same).  0 = no limit (or the ``VT_MAX_RESIDENT_GB`` environment default).
+        The reference keeps one CUDA array per StaticVolume (``volume.py:37-45``)."""
         if data.ndim != 3:
             raise ValueError('Expected a 3D array')
         if edge not in ('texture', 'scipy'):
@@ -56,6 +60,8 @@ class StaticVolume:
                                                      ptr, flags, ctypes.byref(h)), 'vt_volume_create')
             self._handle = h
             self.d_type = np.dtype(np.float32)
+            if max_resident_bytes:
+                self.set_max_resident(int(max_resident_bytes))
         elif device == 'cpu':
             self.data = data
 
@@ -85,6 +91,11 @@ class StaticVolume:
         freed = ctypes.c_uint64()
         _native.check(self._lib.vt_volume_release_copies(self._handle, ctypes.byref(freed)), 'vt_volume_release_copies')
         return int(freed.value)
+
+    def set_max_resident(self, nbytes: int) -> None:
+        """Change the resident-memory budget (bytes, the plain copy included; 0 = none).  See ``__init__``."""
+        if self.device != 'cpu':
+            _native.check(self._lib.vt_volume_set_max_resident(self._handle, ctypes.c_uint64(int(nbytes))), 'vt_volume_set_max_resident')
 
     def synchronize(self) -> None:
         _native.check(self._lib.vt_volume_sync(self._handle), 'vt_volume_sync')
