@@ -162,3 +162,49 @@ def test_huge_cubic_sweep_and_axis_exchanges(interp, huge):
             sv.synchronize()
             assert max_abs_diff(torch, t_out, t_out2) <= tol, (interp, order_rot, 'exchange path')
     sv.close()
+
+
+def test_packed_spans_on_planes_beyond_2_31_bytes_per_box():
+    """the packed-footprint kernels stage a box inside the volume through ONE buffer descriptor based at the box origin,
+    so the 32-bit byte offset of the box's last row must stay below 2^31.  Planes of 4096 x 4128 floats (64.5 MiB) reach that at 32 box
+    planes, which a general rotation whose w axis follows source axis 0 needs for a 16- or 8-deep tile (Lz = 33..45).  The planner must
+    refuse such a box (pick_packed_tile, like plan_block) instead of letting the offset wrap: a wrapped offset lies beyond the descriptor's
+    records, reads 0, and interior tiles come out silently wrong.  A thin volume with such planes, sampled on the plain copy
+    (VT_NO_REORIENT: what the first three calls of a handle, slab handles and a failed reorientation do), forced to the packed family,
+    against the direct kernel."""
+    torch = pytest.importorskip('torch')
+    cu, lds, hbm = _native.device_props(0)
+    if hbm < (64 << 30):
+        pytest.skip('needs ~20 GiB of HBM')
+    shape = (40, 4096, 4096)
+    g = torch.Generator(device='cuda:0')
+    g.manual_seed(4096)
+    vol = torch.rand(shape, dtype=torch.float32, device='cuda:0', generator=g)
+    out = vt.empty(shape, device='gpu:0')
+    out2 = vt.empty(shape, device='gpu:0')
+    t_out = torch.as_tensor(out, device='cuda:0')
+    t_out2 = torch.as_tensor(out2, device='cuda:0')
+    c = np.divide(np.subtract(shape, 1), 2, dtype=np.float32)
+    sv = vt.StaticVolume(vol, interpolation='linear', device='gpu:0')
+    try:
+        for rot in ((0.0, 78.0, 9.0), (5.0, 100.0, 0.0)):
+            m = vt.utils.transform_matrix(rotation=rot, rotation_order='sxyz', center=c)
+            sv.affine(m, output=out, _flags=_native.FORCE_TILED | _native.NO_ZSEP | _native.FORCE_PACKED | _native.NO_REORIENT)
+            k = int(sv.info().last_kernel)
+            lz = int(sv.info().last_lds_dims[0])
+            if k == 6:
+                assert lz * 4096 * 4128 * 4 < 2 ** 31, (rot, lz)                 # a packed box the descriptor can address
+            sv.affine(m, output=out2, _flags=_native.FORCE_DIRECT)
+            sv.synchronize()
+            worst = 0.0
+            for z in range(0, shape[0], 8):
+                worst = max(worst, float((t_out[z:z + 8] - t_out2[z:z + 8]).abs().max().item()))
+            assert worst <= 2e-6, (rot, k, lz, worst)
+            assert float(t_out2.abs().max().item()) > 0.5                         # (the case does sample the volume)
+    finally:
+        sv.close()
+        out.free()
+        out2.free()
+        del vol
+        torch.cuda.empty_cache()
+        _native.free_cached_memory(0)

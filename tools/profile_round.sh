@@ -3,9 +3,9 @@
 #   1. rocprofv3 --kernel-trace --stats          -> per-kernel average durations
 #   2. separate --pmc passes (never combined with tracing): HBM-side traffic, L2 hit rate, SQ issue / wait, LDS conflicts
 # and one summary JSON per command under gpurun_out/profiles_<tag>/ (copy what should be judged into profiles/).
-# usage: tools/profile_round.sh <tag> [case ...]     cases: bench linear512 sweep1024 linear1024 general512 prefilter512 prefilter1024 (default: all)
+# usage: tools/profile_round.sh <tag> [case ...]     cases: bench bench20 linear512 sweep1024 linear1024 general512 axis2_512 prefilter512 prefilter1024 (default: all but bench20)
 tag=${1:-r02}; shift
-cases=${@:-bench linear512 sweep1024 linear1024 general512 prefilter512 prefilter1024}
+cases=${@:-bench linear512 sweep1024 linear1024 general512 axis2_512 prefilter512 prefilter1024}
 export TMPDIR=/tmp
 root=$(pwd)
 out=$root/gpurun_out/profiles_$tag
@@ -40,6 +40,11 @@ for c in $cases; do
     linear1024)    profile linear1024 tools/prof_case.py --size 1024 --interp linear --sweep 6 --iters 30 ;;    # the north star's 1024^3 trilinear sweep
     general512)    profile general512_linear tools/prof_case.py --size 512 --interp linear --general --iters 30
                    profile general512_cubic tools/prof_case.py --size 512 --interp filt_bspline --general --iters 30 ;;
+    # the driver's exact command: kernel stats and `ms_per_step` of its BENCH record are directly comparable
+    bench20)       profile bench20 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-1024 ;;
+    # rotations about array axis 2 (the row kernel, kind 10), 33 degrees
+    axis2_512)     profile axis2_512_linear tools/prof_case.py --size 512 --interp linear --axis2 --angle 33 --iters 30
+                   profile axis2_512_cubic tools/prof_case.py --size 512 --interp filt_bspline --axis2 --angle 33 --iters 30 ;;
     prefilter512)  profile prefilter512 tools/prefilter_time.py 512 ;;
     prefilter1024) profile prefilter1024 tools/prefilter_time.py 1024 ;;
   esac

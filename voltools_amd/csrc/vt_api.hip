@@ -304,22 +304,79 @@ struct PinnedScope {
         if (e != hipSuccess) { (void)hipGetLastError(); return false; }
         return attr.type == hipMemoryTypeHost;
     }
+    // Round 5: only WHOLE 2 MiB units that lie INSIDE the caller's array are registered, and the copies below are cut at the ends of that
+    // interior.  Registration pins and maps pages at the host's own virtual address, and releasing any pinned range takes the mapping
+    // units it touches out of the GPU's page table -- under whatever else is registered in the same unit (the Python layer's pooled
+    // result buffers, the runtime's own temporary pins).  The unit is the host's transparent huge page, 2 MiB, not the 4 KiB page round
+    // 4 still rounded to here (the `Memory access fault by GPU` on a host address of round 4's suite runs): a range
+    // rounded OUTWARD to 4 KiB shares its first and last 2 MiB unit with the caller's neighbouring heap objects, one rounded outward to
+    // 2 MiB would pin memory that is not the caller's.  The interior shares no unit with anything; the ragged head and tail of the array
+    // (< 2 MiB each) travel as ordinary pageable copies through the runtime's staging buffers.
+    char* lo = nullptr;               // the registered interior [lo, hi) of the caller's range
+    char* hi = nullptr;
+    static constexpr uintptr_t kUnit = 2u << 20;
     PinnedScope(const void* p, size_t bytes)
     {
         static const bool off = std::getenv("VT_NO_PIN") != nullptr;
-        if (!off && p && bytes >= (8u << 20) && !already_registered(p)) {
-            // Whole pages only: registration pins and maps pages, and a range that starts or ends inside a page shares that
-            // page with whatever else is registered on it (the Python layer's pooled result buffers, the runtime's own
-            // temporary pins); unregistering one of the overlapping ranges unmaps the shared page under the others -> a GPU
-            // memory access fault on a host address at some later copy.  The first and the last page of
-            // the caller's array are mapped memory of this process, so rounding outward is safe.
-            constexpr uintptr_t kPage = 4096;
-            const uintptr_t a0 = reinterpret_cast<uintptr_t>(p) & ~(kPage - 1);
-            const uintptr_t a1 = (reinterpret_cast<uintptr_t>(p) + bytes + kPage - 1) & ~(kPage - 1);
-            ptr = reinterpret_cast<void*>(a0);
-            pinned = hipHostRegister(ptr, a1 - a0, hipHostRegisterDefault) == hipSuccess;
-            if (!pinned) (void)hipGetLastError();
+        if (off || !p || bytes < (8u << 20) || already_registered(p)) return;
+        const uintptr_t a0 = (reinterpret_cast<uintptr_t>(p) + kUnit - 1) & ~(kUnit - 1);
+        const uintptr_t a1 = (reinterpret_cast<uintptr_t>(p) + bytes) & ~(kUnit - 1);
+        if (a1 <= a0 || a1 - a0 < (4u << 20) || already_registered(reinterpret_cast<const void*>(a0))) return;
+        ptr = reinterpret_cast<void*>(a0);
+        pinned = hipHostRegister(ptr, a1 - a0, hipHostRegisterDefault) == hipSuccess;
+        if (!pinned) { (void)hipGetLastError(); return; }
+        lo = reinterpret_cast<char*>(a0);
+        hi = reinterpret_cast<char*>(a1);
+    }
+    // A copy between device memory and a part of the caller's range, cut so that every piece lies either wholly inside the registered
+    // interior or wholly outside it: the runtime decides "pinned or pageable" from a transfer's first host byte, and a pinned transfer
+    // that runs past the end of the registration would let the DMA engine read unmapped pages.  `host` may be the source or the target.
+    hipError_t copy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t st) const
+    {
+        if (!pinned || bytes == 0) return hipMemcpyAsync(dst, src, bytes, kind, st);
+        const bool h2d = kind == hipMemcpyHostToDevice;
+        const char* const h0 = h2d ? static_cast<const char*>(src) : static_cast<const char*>(dst);
+        const char* const h1 = h0 + bytes;
+        const char* cuts[4] = {h0, std::min(std::max(h0, (const char*)lo), h1), std::min(std::max(h0, (const char*)hi), h1), h1};
+        for (int i = 0; i < 3; ++i) {
+            const size_t off = (size_t)(cuts[i] - h0), len = (size_t)(cuts[i + 1] - cuts[i]);
+            if (!len) continue;
+            const hipError_t e = hipMemcpyAsync(static_cast<char*>(dst) + off, static_cast<const char*>(src) + off, len, kind, st);
+            if (e != hipSuccess) return e;
         }
+        return hipSuccess;
+    }
+    // ... and the pitched form: `rows` dense host rows of `row_bytes` to / from device rows `dpitch` apart.  Whole rows inside / outside
+    // the interior go as 2-D copies, a row that straddles one of its ends is cut there.
+    hipError_t copy2d(void* dev, size_t dpitch, const void* host, size_t row_bytes, size_t rows, bool h2d, hipStream_t st) const
+    {
+        const hipMemcpyKind kind = h2d ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
+        auto block = [&](size_t r0, size_t r1) -> hipError_t {
+            if (r1 <= r0) return hipSuccess;
+            char* d = static_cast<char*>(dev) + r0 * dpitch;
+            const char* h = static_cast<const char*>(host) + r0 * row_bytes;
+            return h2d ? hipMemcpy2DAsync(d, dpitch, h, row_bytes, row_bytes, r1 - r0, kind, st)
+                       : hipMemcpy2DAsync(const_cast<char*>(h), row_bytes, d, dpitch, row_bytes, r1 - r0, kind, st);
+        };
+        auto one_row = [&](size_t r) -> hipError_t {          // through copy(): cut at the interior's ends
+            char* d = static_cast<char*>(dev) + r * dpitch;
+            const char* h = static_cast<const char*>(host) + r * row_bytes;
+            return h2d ? copy(d, h, row_bytes, kind, st) : copy(const_cast<char*>(h), d, row_bytes, kind, st);
+        };
+        if (!pinned || rows == 0 || row_bytes == 0) return block(0, rows);
+        const char* const h0 = static_cast<const char*>(host);
+        auto row_of = [&](const char* a) { return a <= h0 ? (size_t)0 : std::min(rows, (size_t)(a - h0) / row_bytes); };   // row that holds byte a
+        // rows [0, ra): wholly below lo; row ra may straddle lo; rows (ra', rb): wholly inside; row rb may straddle hi; rows beyond: outside
+        const size_t ra = row_of(lo), rb = row_of(hi);
+        const bool cut_a = ra < rows && h0 + ra * row_bytes < lo;                              // row ra starts below lo
+        const size_t in0 = cut_a ? ra + 1 : ra;
+        const bool cut_b = rb < rows && rb >= in0 && h0 + rb * row_bytes < hi;                 // row rb starts inside and ends beyond hi
+        hipError_t e = block(0, ra);
+        if (e == hipSuccess && cut_a) e = one_row(ra);
+        if (e == hipSuccess) e = block(in0, std::max(in0, rb));
+        if (e == hipSuccess && cut_b) e = one_row(rb);
+        if (e == hipSuccess) e = block(std::max(in0, cut_b ? rb + 1 : rb), rows);
+        return e;
     }
     ~PinnedScope() { if (pinned && hipHostUnregister(ptr) != hipSuccess) (void)hipGetLastError(); }
 };
@@ -740,7 +797,8 @@ int try_rows(vt_volume* v, const double m[12], int flags, AffineParams* p, TileP
     TilePlan plans = TilePlan();
     plans.kind = 0;
     if (!plan_rows(v, m, flags, &ps, &plans) || plans.kind != 10) return 0;
-    if (is_cubic(v->interp) && !v->d_src_xe) {
+    const bool use_xe = is_cubic(v->interp) && !(ps.flags & (1 << 16));      // (a fractional axis-2 offset forms its own x-sums on the plain copy)
+    if (use_xe && !v->d_src_xe) {
         if (v->xe_retry_in > 0) { --v->xe_retry_in; return 0; }
         const size_t bytes = (size_t)v->D * v->H * v->P * sizeof(float);
         if (alloc_lazy(v, kCopyXe, bytes, kCopyXe, -1) != hipSuccess) {
@@ -761,8 +819,8 @@ int try_rows(vt_volume* v, const double m[12], int flags, AffineParams* p, TileP
         lazy_build_end(v);
     }
     *p = ps; *plan = plans;
-    if (is_cubic(v->interp)) touch_lazy(v, kCopyXe);
-    ori->src_plain = is_cubic(v->interp) ? v->d_src_xe : v->d_src;
+    if (use_xe) touch_lazy(v, kCopyXe);
+    ori->src_plain = use_xe ? v->d_src_xe : v->d_src;
     return 0;
 }
 
@@ -993,7 +1051,7 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
                                   (int64_t)v->oH * v->oW, v->oW, v->stream));
     if (host_out) {
         PinnedScope pin(out, n_out * sizeof(float));
-        VT_HIP(hipMemcpyAsync(out, d_final, n_out * sizeof(float), hipMemcpyDeviceToHost, v->stream));
+        VT_HIP(pin.copy(out, d_final, n_out * sizeof(float), hipMemcpyDeviceToHost, v->stream));
         VT_HIP(hipStreamSynchronize(v->stream));
     }
     return 0;
@@ -1119,7 +1177,7 @@ int create_common(int dev, int D, int H, int W, int interp, const float* data, i
         hipError_t ec;
         {
             PinnedScope pin((cflags & VT_SRC_DEVICE) ? nullptr : data, (cflags & VT_SRC_DEVICE) ? 0 : ubytes);
-            ec = hipMemcpyAsync(d_dense, data, ubytes, kind, v->stream);
+            ec = (cflags & VT_SRC_DEVICE) ? hipMemcpyAsync(d_dense, data, ubytes, kind, v->stream) : pin.copy(d_dense, data, ubytes, kind, v->stream);
             if (ec == hipSuccess) ec = launch_mirror_pad(d_dense, v->d_src, uD, uH, uW, pad, v->P, v->stream);
             if (ec == hipSuccess) ec = hipStreamSynchronize(v->stream);
         }
@@ -1134,8 +1192,11 @@ int create_common(int dev, int D, int H, int W, int interp, const float* data, i
     VT_HIPC(hipMemset2DAsync(v->d_src + W, (size_t)v->P * sizeof(float), 0, (size_t)(v->P - W) * sizeof(float), (size_t)D * H, v->stream));
     {
         PinnedScope pin((cflags & VT_SRC_DEVICE) ? nullptr : data, (cflags & VT_SRC_DEVICE) ? 0 : (size_t)D * H * W * sizeof(float));
-        VT_HIPC(hipMemcpy2DAsync(v->d_src, (size_t)v->P * sizeof(float), data, (size_t)W * sizeof(float),
-                                 (size_t)W * sizeof(float), (size_t)D * H, kind, v->stream));
+        if (cflags & VT_SRC_DEVICE)
+            VT_HIPC(hipMemcpy2DAsync(v->d_src, (size_t)v->P * sizeof(float), data, (size_t)W * sizeof(float),
+                                     (size_t)W * sizeof(float), (size_t)D * H, kind, v->stream));
+        else
+            VT_HIPC(pin.copy2d(v->d_src, (size_t)v->P * sizeof(float), data, (size_t)W * sizeof(float), (size_t)D * H, true, v->stream));
         VT_HIPC(hipStreamSynchronize(v->stream));
     }
 
@@ -1277,8 +1338,8 @@ int oneshot_pipelined(int dev, const float* h_volume, int D, int H, int W, int i
     for (int k = 0; k < nch; ++k) {
         const int z0 = k * Dc, z1 = std::min(D, z0 + Dc);
         if (z0 < z1)
-            VT_HIPP(hipMemcpy2DAsync(v->d_src + (size_t)z0 * H * v->P, (size_t)v->P * sizeof(float), h_volume + (size_t)z0 * H * W,
-                                     (size_t)W * sizeof(float), (size_t)W * sizeof(float), (size_t)(z1 - z0) * H, hipMemcpyHostToDevice, s_up));
+            VT_HIPP(pin_in.copy2d(v->d_src + (size_t)z0 * H * v->P, (size_t)v->P * sizeof(float), h_volume + (size_t)z0 * H * W,
+                                  (size_t)W * sizeof(float), (size_t)(z1 - z0) * H, true, s_up));
         VT_HIPP(hipEventRecord(ev_up[(size_t)k], s_up));
     }
     const double t_uploads = now_ms();
@@ -1334,8 +1395,8 @@ int oneshot_pipelined(int dev, const float* h_volume, int D, int H, int W, int i
     for (int j = 0; j < nslabs; ++j) {
         const int d0 = j * Dc, d1 = std::min(D, d0 + Dc);
         VT_HIPP(hipEventSynchronize(ev_k[(size_t)j]));
-        VT_HIPP(hipMemcpyAsync(h_out + (size_t)d0 * H * W, d_out + (size_t)d0 * H * W, (size_t)(d1 - d0) * H * W * sizeof(float),
-                               hipMemcpyDeviceToHost, s_dn));
+        VT_HIPP(pin_out.copy(h_out + (size_t)d0 * H * W, d_out + (size_t)d0 * H * W, (size_t)(d1 - d0) * H * W * sizeof(float),
+                             hipMemcpyDeviceToHost, s_dn));
         if (trace) VT_HIPP(hipEventRecord(ev_dn[(size_t)j], s_dn));
     }
     const double t_slabs = now_ms();
@@ -1413,7 +1474,7 @@ int do_affine_batch(vt_volume* v, int n, const double* m4x4s, float* out, int fl
     v->last_lds_bytes = 0; v->last_grid = (int)((n_out + 255) / 256);
     if (host_out) {
         PinnedScope pin(out, total * sizeof(float));
-        VT_HIP(hipMemcpyAsync(out, d_out, total * sizeof(float), hipMemcpyDeviceToHost, v->stream));
+        VT_HIP(pin.copy(out, d_out, total * sizeof(float), hipMemcpyDeviceToHost, v->stream));
         VT_HIP(hipStreamSynchronize(v->stream));
     }
     return 0;
@@ -1688,8 +1749,11 @@ int vt_volume_upload_planes(vt_volume_t* v, int first_plane, int nplanes, const 
     const bool src_dev = (flags & VT_SRC_DEVICE) != 0;
     const size_t rows = (size_t)nplanes * v->H;
     PinnedScope pin(src_dev ? nullptr : data, src_dev ? 0 : rows * v->W * sizeof(float));
-    VT_HIP(hipMemcpy2DAsync(v->d_src + (size_t)first_plane * v->H * v->P, (size_t)v->P * sizeof(float), data, (size_t)v->W * sizeof(float),
-                            (size_t)v->W * sizeof(float), rows, src_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, v->stream));
+    if (src_dev)
+        VT_HIP(hipMemcpy2DAsync(v->d_src + (size_t)first_plane * v->H * v->P, (size_t)v->P * sizeof(float), data, (size_t)v->W * sizeof(float),
+                                (size_t)v->W * sizeof(float), rows, hipMemcpyDeviceToDevice, v->stream));
+    else
+        VT_HIP(pin.copy2d(v->d_src + (size_t)first_plane * v->H * v->P, (size_t)v->P * sizeof(float), data, (size_t)v->W * sizeof(float), rows, true, v->stream));
     VT_HIP(hipStreamSynchronize(v->stream));
     return 0;
 }

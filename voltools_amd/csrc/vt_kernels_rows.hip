@@ -1,4 +1,4 @@
-// vt_kernels_rows.hip -- kind 10: maps that leave axis 2 alone, src_w = w + t with an integer t that is a multiple of four
+// vt_kernels_rows.hip -- kind 10: maps that leave axis 2 alone, src_w = w + t (any t since round 5: integer or fractional)
 // ([a b 0 t0; c e 0 t1; 0 0 1 t]: every rotation about axis 2 through the default centre, scaled / sheared or not in the (d, h) plane).
 //
 // The resident plain layout [z][y][x] is, for these maps, what the plane-quad copy is for rotations about axis 0: the axis the map
@@ -49,12 +49,25 @@ hipError_t launch_relayout_xfir(const float* src, float* dst, int D, int H, int 
     return hipGetLastError();
 }
 
-// KIND 0: trilinear (2 x 2 rows of the plain copy), KIND 1: cubic (4 x 4 rows of the x-convolved copy; flag bit 18: `_simple` weights)
-template <int KIND, int PD>
+// KIND 0: trilinear, integer axis-2 offset (2 x 2 rows of the plain copy, one tap per row)
+// KIND 1: cubic, integer offset (4 x 4 rows of the x-convolved copy, one tap per row; flag bit 18: `_simple` weights)
+// KIND 2: trilinear, fractional offset (two taps per row, the x-lerp of direct_sample)
+// KIND 3: cubic, fractional offset (4 x 4 rows of the PLAIN copy, four taps per row with the lane's own x weights)
+// NV: 16-byte vectors staged per row -- 16 where the run starts on a vector of the source row (integer offset that is a multiple of four:
+// the rotation about axis 2 through the default centre), 18 otherwise: the run starts up to three floats into its first vector and the
+// fractional kinds read one (trilinear) or three (cubic) columns beyond the 64.  Any other offset used to take the axis exchange path
+// (exchanged copy + plane-quad kernel + transpose pass, 0.43 ms at 512^3 against 0.31); the reference's kernel has no such cliff
+// (transforms.py:269-274).
+template <int KIND, int PD, int NV>
 __global__ __launch_bounds__(64 * PD) void affine_rows(const float* __restrict__ src, float* __restrict__ out, const float* __restrict__ zeros16,
                                                    const AffineParams p)
 {
-    constexpr int HALO = KIND == 0 ? 0 : 1, NT = KIND == 0 ? 2 : 4;
+    constexpr bool CUBIC = (KIND & 1) != 0, FRAC = KIND >= 2;
+    constexpr int HALO = CUBIC ? 1 : 0, NT = CUBIC ? 4 : 2;
+    constexpr int NX = !FRAC ? 1 : (CUBIC ? 4 : 2);            // taps per row along x
+    constexpr int XH = (FRAC && CUBIC) ? 1 : 0;                // columns in front of floor(src_w) that a lane taps
+    constexpr int RS = 4 * NV;                                 // staged floats per row
+    constexpr unsigned RSB = 16u * NV;                         // ... in bytes
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int run = blockIdx.x, th_i = blockIdx.y, td_i = blockIdx.z;
@@ -73,8 +86,8 @@ __global__ __launch_bounds__(64 * PD) void affine_rows(const float* __restrict__
         hi[r] = base[r] + p.pos[r];
         any_valid = any_valid && (hi[r] >= p.vlo[r] - kTileMargin) && (lo[r] < p.vhi[r] + kTileMargin);
     }
-    const int t2 = p.zoff;                        // src_w = w + t2 (the planner's integer multiple of four)
-    any_valid = any_valid && ((double)(w0 + kRowRun - 1 + t2) >= p.vlo[2] - kTileMargin) && ((double)(w0 + t2) < p.vhi[2] + kTileMargin);
+    const int t2 = p.zoff;                        // floor of the axis-2 offset: src_w = w + t2 (+ a fraction for the kinds 2 / 3)
+    any_valid = any_valid && ((double)(w0 + kRowRun + t2) >= p.vlo[2] - kTileMargin) && ((double)(w0 + t2) < p.vhi[2] + kTileMargin);
     const int w = w0 + lane;
     if (!any_valid) {
         if (!keep && w < p.oW) {
@@ -86,22 +99,27 @@ __global__ __launch_bounds__(64 * PD) void affine_rows(const float* __restrict__
     }
     int oz, oy;
     {
-        const int f0 = (int)floor(lo[0]), f1 = (int)floor(lo[1]);
+        // The box origin lies 1e-9 below the tile's lowest coordinate (and the planner sizes the box for an extent 1e-8 larger): a pixel's
+        // own fma chain may round across an integer the tile corners' chain did not -- by 1e-13 at most --, and its taps must still index
+        // inside the box.  (Until round 5 such a pixel would have read its taps from global memory: a path no test ever reached.)
+        const int f0 = (int)floor(lo[0] - 1.0e-9), f1 = (int)floor(lo[1] - 1.0e-9);
         // (the builtin, not an inline-asm v_readfirstlane: the compiler's hazard recogniser does not look into asm statements -- no wait
         //  state between the v_cvt_i32_f64 that produces the value and the lane read of it --, and the cubic instantiation got a stale
         //  origin in some waves: rows staged by different waves then disagreed and results changed from launch to launch)
         oz = __builtin_amdgcn_readfirstlane(f0) - HALO;
         oy = __builtin_amdgcn_readfirstlane(f1) - HALO;
     }
+    // first staged column: the vector that holds the run's first tap (a multiple of four; for NV = 16 that tap itself)
+    const int x0 = (w0 + t2 - XH) & ~3;
 
-    // ---- stage Lz x Ly source rows, 64 floats each (16 vectors of 16 bytes): vector v lands at lds + 16 v ----
+    // ---- stage Lz x Ly source rows, NV vectors of 16 bytes each: vector v lands at lds + 16 v ----
     {
-        const int total = Lz * Ly * 16;
-        const int x0 = w0 + t2;                   // multiple of 4: whole vectors are inside or outside the row
+        const int total = Lz * Ly * NV;
         const int wave_first = __builtin_amdgcn_readfirstlane(tid & ~63);
         for (int vb = wave_first; vb < total; vb += NTHR) {
             const int v = vb + lane;
-            const int row = v >> 4, seg = v & 15;
+            const int row = NV == 16 ? (v >> 4) : (int)__umulhi((unsigned)v, 0x0E38E38Fu);      // v / 18 for v < 2^24 (ceil(2^32 / 18))
+            const int seg = v - row * NV;
             const int zz = (int)__umulhi((unsigned)row, p.psv_magic);        // row / Ly (host constant: floor(2^32 / Ly) + 1)
             const int yy = row - zz * Ly;
             const int gz = oz + zz, gy = oy + yy, gx = x0 + 4 * seg;
@@ -123,18 +141,15 @@ __global__ __launch_bounds__(64 * PD) void affine_rows(const float* __restrict__
     const double fzd = floor(s0), fyd = floor(s1);
     const float fz = (float)(s0 - fzd), fy = (float)(s1 - fyd);
     float wy[4] = {0.f, 0.f, 0.f, 0.f}, wz[4] = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (KIND != 0) {
+    if constexpr (CUBIC) {
         if (p.flags & (1 << 18)) { cubic_weights<true>(fy, wy); cubic_weights<true>(fz, wz); }
         else { cubic_weights<false>(fy, wy); cubic_weights<false>(fz, wz); }
     }
-    const int rz_l = (int)fzd - HALO - oz, ry_l = (int)fyd - HALO - oy;
-    // (the box is sized from the tile's corners with one row of slack; a pixel whose own chain rounds across an integer the corners'
-    //  did not could still miss it by a row: such a pixel reads its taps from global memory -- never seen)
-    const int in_box_l = (rz_l >= 0 && ry_l >= 0 && rz_l + NT <= Lz && ry_l + NT <= Ly) ? 1 : 0;
+    const int rz_l = (int)fzd - HALO - oz, ry_l = (int)fyd - HALO - oy;       // inside the box by construction (see the origin above)
     const int in_zy_l = ((s0 >= p.vlo[0]) && (s0 < p.vhi[0]) && (s1 >= p.vlo[1]) && (s1 < p.vhi[1]) && hl < p.oH && d < p.oD) ? 1 : 0;
     // ... and leaves them in LDS, 16 dwords per pixel behind the staged rows (every lane of the wave reads them back from one address: a
     // broadcast).  (Taking them across lanes with v_readlane instead gave results that changed from launch to launch.)
-    float* const prm = lds + Lz * Ly * kRowRun + (wv * kRowPH) * 16;
+    float* const prm = lds + Lz * Ly * RS + (wv * kRowPH) * 16;
     if (lane < kRowPH) {
         float* q = prm + lane * 16;
         typedef float v4f __attribute__((ext_vector_type(4)));
@@ -143,16 +158,27 @@ __global__ __launch_bounds__(64 * PD) void affine_rows(const float* __restrict__
         typedef int v4i __attribute__((ext_vector_type(4)));
         // (integers travel as integers: a small integer's bit pattern is a subnormal float, and float moves may flush it)
         *reinterpret_cast<v4f*>(q + 8) = v4f{fy, fz, 0.f, 0.f};
-        *reinterpret_cast<v4i*>(q + 12) = v4i{rz_l * Ly + ry_l, in_zy_l | (in_box_l << 1), rz_l, ry_l};
+        *reinterpret_cast<v4i*>(q + 12) = v4i{rz_l * Ly + ry_l, in_zy_l, rz_l, ry_l};
     }
+
+    // the lane's own column: src_w by the canonical chain of row 2 (fma(0, d, fma(0, h, fma(1, w, t)))), its floor and float32 fraction,
+    // the x weights of a fractional cubic offset -- exactly what affine_direct forms per voxel
+    const double sw = (double)w + p.m[11];
+    const bool in_x = (sw >= p.vlo[2]) && (sw < p.vhi[2]);
+    const double fxd = floor(sw);
+    const float fx = (float)(sw - fxd);
+    float wx[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (FRAC && CUBIC) {
+        if (p.flags & (1 << 18)) cubic_weights<true>(fx, wx); else cubic_weights<false>(fx, wx);
+    }
+    int col = (int)fxd - XH - x0;                                              // 0 .. 3 + lane for every lane whose column matters
+    col = min(max(col, 0), RS - NX);                                           // (lanes beyond the output's width: any column of the row)
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     if (d >= p.oD) return;
-    const double sw = (double)w + p.m[11];        // == fma(0, d, fma(0, h, fma(1, w, t))) of the canonical chain
-    const bool in_x = (sw >= p.vlo[2]) && (sw < p.vhi[2]);
-    const unsigned lds_b = lds_byte_address(lds) + 4u * (unsigned)lane;
+    const unsigned lds_b = lds_byte_address(lds) + 4u * (unsigned)col;
     float* optr = out + ((int64_t)d * p.oH + h0) * p.oW + w;
 #pragma unroll
     for (int i = 0; i < kRowPH; ++i) {
@@ -164,28 +190,30 @@ __global__ __launch_bounds__(64 * PD) void affine_rows(const float* __restrict__
         const v4f pf = *reinterpret_cast<const v4f*>(prm + i * 16 + 8);
         typedef int v4i __attribute__((ext_vector_type(4)));
         const v4i pi = *reinterpret_cast<const v4i*>(prm + i * 16 + 12);
-        const int fl = __builtin_amdgcn_readfirstlane(pi[1]);
-        const bool inside_zy = (fl & 1) != 0;
+        const bool inside_zy = (__builtin_amdgcn_readfirstlane(pi[1]) & 1) != 0;
         float val = 0.f;
         if (inside_zy) {
-            const bool in_box = (fl & 2) != 0;
-            const unsigned a0 = lds_b + 256u * (unsigned)__builtin_amdgcn_readfirstlane(pi[0]);
+            const unsigned a0 = lds_b + RSB * (unsigned)__builtin_amdgcn_readfirstlane(pi[0]);
             float t[NT][NT];
-            if (in_box) {
 #pragma unroll
-                for (int c = 0; c < NT; ++c)
+            for (int c = 0; c < NT; ++c)
 #pragma unroll
-                    for (int b = 0; b < NT; ++b)
-                        t[c][b] = *reinterpret_cast<const __attribute__((address_space(3))) float*>((size_t)(a0 + 256u * (unsigned)(c * Ly + b)));
-            } else {
-                const int gz = oz + __builtin_amdgcn_readfirstlane(pi[2]);
-                const int gy = oy + __builtin_amdgcn_readfirstlane(pi[3]);
-#pragma unroll
-                for (int c = 0; c < NT; ++c)
-#pragma unroll
-                    for (int b = 0; b < NT; ++b) t[c][b] = fetch0(src, p, gz + c, gy + b, w + t2);
-            }
-            if constexpr (KIND == 0) {
+                for (int b = 0; b < NT; ++b) {
+                    const unsigned ra = a0 + RSB * (unsigned)(c * Ly + b);
+                    auto tap = [&](int k) { return *reinterpret_cast<const __attribute__((address_space(3))) float*>((size_t)(ra + 4u * (unsigned)k)); };
+                    if constexpr (NX == 1) {
+                        t[c][b] = tap(0);
+                    } else if constexpr (NX == 2) {
+                        const float a = tap(0), bb = tap(1);
+                        t[c][b] = fmaf(fx, bb - a, a);                         // direct_sample's x-lerp
+                    } else {
+                        float accx = wx[0] * tap(0);                           // direct_sample's x-sum
+                        accx = fmaf(wx[1], tap(1), accx);
+                        accx = fmaf(wx[2], tap(2), accx);
+                        t[c][b] = fmaf(wx[3], tap(3), accx);
+                    }
+                }
+            if constexpr (!CUBIC) {
                 const float y0 = fmaf(pf[0], t[0][1] - t[0][0], t[0][0]);
                 const float y1 = fmaf(pf[0], t[1][1] - t[1][0], t[1][0]);
                 val = fmaf(pf[1], y1 - y0, y0);
@@ -207,28 +235,39 @@ __global__ __launch_bounds__(64 * PD) void affine_rows(const float* __restrict__
 }
 
 typedef void (*rows_fn)(const float*, float*, const float*, const AffineParams);
-static rows_fn rows_entry(int kind, int pd)
+template <int PD>
+static rows_fn rows_entry_pd(int kind, int nv)
 {
-    if (pd == 8) return kind == 0 ? affine_rows<0, 8> : affine_rows<1, 8>;
-    return kind == 0 ? affine_rows<0, 4> : affine_rows<1, 4>;
+    if (nv == 16) return kind == 0 ? affine_rows<0, PD, 16> : affine_rows<1, PD, 16>;
+    switch (kind) {
+        case 0: return affine_rows<0, PD, 18>;
+        case 1: return affine_rows<1, PD, 18>;
+        case 2: return affine_rows<2, PD, 18>;
+        default: return affine_rows<3, PD, 18>;
+    }
 }
+static rows_fn rows_entry(int kind, int pd, int nv) { return pd == 8 ? rows_entry_pd<8>(kind, nv) : rows_entry_pd<4>(kind, nv); }
 
 hipError_t init_rows_kernels()
 {
-    for (int kind = 0; kind < 2; ++kind)
-        for (int pd = 4; pd <= 8; pd += 4) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rows_entry(kind, pd)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-        }
+    for (int kind = 0; kind < 4; ++kind)
+        for (int pd = 4; pd <= 8; pd += 4)
+            for (int nv = 16; nv <= 18; nv += 2) {
+                if (nv == 16 && kind >= 2) continue;
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rows_entry(kind, pd, nv)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return e;
+            }
     return hipSuccess;
 }
 
 void rows_tile(int* ph, int* run) { *ph = kRowPH; *run = kRowRun; }
 
+// p.Lx: staged floats per row (64 or 72); flag bit 16: the axis-2 offset has a fraction (kinds 2 / 3)
 hipError_t launch_affine_rows(int interp, int pd, const float* src, float* out, const float* zeros16, const AffineParams& p, int lds_bytes, hipStream_t stream)
 {
     const dim3 g((unsigned)((p.oW + kRowRun - 1) / kRowRun), (unsigned)((p.oH + kRowPH - 1) / kRowPH), (unsigned)((p.oD + pd - 1) / pd));
-    hipLaunchKernelGGL(rows_entry(interp_kind(interp) == 0 ? 0 : 1, pd), g, dim3(64 * pd), lds_bytes, stream, src, out, zeros16, p);
+    const int kind = (interp_kind(interp) == 0 ? 0 : 1) + ((p.flags & (1 << 16)) ? 2 : 0);
+    hipLaunchKernelGGL(rows_entry(kind, pd, p.Lx == 64 ? 16 : 18), g, dim3(64 * pd), lds_bytes, stream, src, out, zeros16, p);
     return hipGetLastError();
 }
 

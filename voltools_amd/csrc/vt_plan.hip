@@ -1098,8 +1098,13 @@ bool plan_rows(const vt_volume* v, const double m[12], int flags, AffineParams* 
     // has the plane-quad kernel: pure translations, the identity)
     if (!(m[2] == 0.0 && m[6] == 0.0 && m[8] == 0.0 && m[9] == 0.0 && m[10] == 1.0)) return false;
     if (m[0] == 1.0 && m[1] == 0.0 && m[4] == 0.0) return false;
+    // any finite offset along axis 2 (round 5): a multiple of four starts a run on a 16-byte vector of the source row (16 vectors per
+    // row), every other offset stages 18; a fractional one adds the x taps of the interpolation (vt_kernels_rows.hip: kinds 2 / 3)
     const double t = m[11];
-    if (!(std::fabs(t) < 1.0e9) || t != std::floor(t) || ((int64_t)t & 3) != 0) return false;
+    if (!(std::fabs(t) < 1.0e9)) return false;
+    const double tfl = std::floor(t);
+    const bool frac = t != tfl;
+    const int nv = (!frac && ((int64_t)tfl & 3) == 0) ? 16 : 18;
     for (int i = 0; i < 12; ++i) if (!(std::fabs(m[i]) < 1.0e9)) return false;
     int ph, run;
     rows_tile(&ph, &run);
@@ -1114,20 +1119,20 @@ bool plan_rows(const vt_volume* v, const double m[12], int flags, AffineParams* 
         for (int r = 0; r < 2 && ok; ++r) {
             const double ext = std::fabs(m[4 * r]) * (cand - 1) + std::fabs(m[4 * r + 1]) * (ph - 1);
             ok = ext < 200.0;
-            L[r] = (int)std::floor(ext) + 3 + halo2;      // floor(hi) - floor(lo) <= floor(ext) + 1, + 1 upper tap, + 1 slack
+            L[r] = (int)std::floor(ext + 1.0e-8) + 3 + halo2;      // floor(hi) - floor(lo - 1e-9) <= floor(ext + 1e-8) + 1, + 1 upper tap, + 1 slack
         }
-        lds = L[0] * L[1] * run * 4 + cand * ph * 16 * 4;  // the staged rows + 16 dwords per pixel (one wave per d, eight pixels each)
+        lds = L[0] * L[1] * 4 * nv * 4 + cand * ph * 16 * 4;  // the staged rows + 16 dwords per pixel (one wave per d, eight pixels each)
         if (ok && lds <= 64 * 1024 && lds <= v->lds_limit) pd = cand;      // (strong minification in the (d, h) plane: the general kernels serve it)
     }
     if (pd == 0) return false;
     plan_prepare(v, m, flags, p, plan);
     const int T[3] = {pd, ph, 1};
     set_tile_reach(p, m, T, 0);
-    p->Lz = L[0]; p->Ly = L[1]; p->Lx = run; p->Lx_used = run;
+    p->Lz = L[0]; p->Ly = L[1]; p->Lx = 4 * nv; p->Lx_used = run;
     p->psv_magic = (uint32_t)(4294967296.0 / (double)L[1]) + 1u;
-    p->zoff = (int32_t)t;
+    p->zoff = (int32_t)tfl;
     p->fz = 0.0f;
-    p->flags = (flags & VT_KEEP_OUTSIDE);
+    p->flags = (flags & VT_KEEP_OUTSIDE) | (frac ? (1 << 16) : 0);
     if (v->interp == VT_BSPLINE_SIMPLE || v->interp == VT_FILT_BSPLINE_SIMPLE) p->flags |= (1 << 18);
     plan->kind = 10; plan->cfg = 0; plan->td = pd; plan->th = ph; plan->tw = run;
     plan->lds_bytes = lds;
