@@ -234,6 +234,190 @@ __global__ __launch_bounds__(64 * PD) void affine_rows(const float* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The same tile walking ALL its runs of 64 w with two row buffers (round 5): the box of source rows (z, y) a pixel tile taps does not
+// depend on w, so the tile's geometry and its pixels' parameters are worked out once, and run k+1 is staged while run k is computed.
+// [counters of the one-run-per-workgroup form, profiles/r05_axis2_512_*_summary.json] HBM-side traffic 0.99-1.00 GB (0.93x algorithmic: only
+// the part of the source the output maps to is read), no LDS conflicts, but SQ_WAIT_ANY is 50 % of the wave cycles: stage -> wait for every
+// byte -> one barrier -> compute, nothing overlapping inside a workgroup.  Here: one barrier per run, a counted `s_waitcnt vmcnt(8)` -- every
+// pixel issues exactly one store per wave, lanes that must not write carry an offset beyond the output descriptor's records, so the eight
+// stores of a run are always eight instructions behind the next run's staging loads and may stay in flight while those are waited for.
+// ---------------------------------------------------------------------------------------------------
+template <int KIND, int PD, int NV>
+__global__ __launch_bounds__(64 * PD) void affine_rows_db(const float* __restrict__ src, float* __restrict__ out, const float* __restrict__ zeros16,
+                                                      const AffineParams p)
+{
+    constexpr bool CUBIC = (KIND & 1) != 0, FRAC = KIND >= 2;
+    constexpr int HALO = CUBIC ? 1 : 0, NT = CUBIC ? 4 : 2;
+    constexpr int NX = !FRAC ? 1 : (CUBIC ? 4 : 2);
+    constexpr int XH = (FRAC && CUBIC) ? 1 : 0;
+    constexpr int RS = 4 * NV;
+    constexpr unsigned RSB = 16u * NV;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int th_i = blockIdx.x, td_i = blockIdx.y;
+    constexpr int NTHR = 64 * PD;
+    const int d0 = td_i * PD, h0 = th_i * kRowPH;
+    const int Ly = p.Ly, Lz = p.Lz;
+    const bool keep = (p.flags & VT_KEEP_OUTSIDE) != 0;
+    const int nruns = (p.oW + kRowRun - 1) / kRowRun;
+    const int d = d0 + wv;
+
+    double base[2], lo[2], hi[2];
+    bool any_valid = true;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        base[r] = fma(p.m[4 * r], (double)d0, fma(p.m[4 * r + 1], (double)h0, p.m[4 * r + 3]));
+        lo[r] = base[r] + p.neg[r];
+        hi[r] = base[r] + p.pos[r];
+        any_valid = any_valid && (hi[r] >= p.vlo[r] - kTileMargin) && (lo[r] < p.vhi[r] + kTileMargin);
+    }
+    if (!any_valid) {
+        // no pixel of the tile maps inside the valid (z, y) interval, whatever w: zero-fill its rows (or leave them untouched)
+        if (!keep && d < p.oD)
+            for (int i = 0; i < kRowPH && h0 + i < p.oH; ++i) {
+                float* row = out + ((int64_t)d * p.oH + (h0 + i)) * p.oW;
+                for (int w = lane; w < p.oW; w += 64) row[w] = 0.0f;
+            }
+        return;
+    }
+    int oz, oy;
+    {
+        const int f0 = (int)floor(lo[0] - 1.0e-9), f1 = (int)floor(lo[1] - 1.0e-9);       // (see affine_rows)
+        oz = __builtin_amdgcn_readfirstlane(f0) - HALO;
+        oy = __builtin_amdgcn_readfirstlane(f1) - HALO;
+    }
+    const int t2 = p.zoff;
+    const int box_floats = Lz * Ly * RS;
+    float* const prm = lds + 2 * box_floats + (wv * kRowPH) * 16;
+    const int wave_first = __builtin_amdgcn_readfirstlane(tid & ~63);
+    const int total = Lz * Ly * NV;
+
+    // stage run r into buffer r & 1: NV vectors per row from column x0(r) on; vectors outside the volume come from a block of zeros
+    auto stage = [&](int r) {
+        const int x0 = (r * kRowRun + t2 - XH) & ~3;
+        float* const dstb = lds + (r & 1) * box_floats;
+        for (int vb = wave_first; vb < total; vb += NTHR) {
+            const int v = vb + lane;
+            const int row = NV == 16 ? (v >> 4) : (int)__umulhi((unsigned)v, 0x0E38E38Fu);
+            const int seg = v - row * NV;
+            const int zz = (int)__umulhi((unsigned)row, p.psv_magic);
+            const int yy = row - zz * Ly;
+            const int gz = oz + zz, gy = oy + yy, gx = x0 + 4 * seg;
+            const bool inb = (unsigned)gz < (unsigned)p.sD && (unsigned)gy < (unsigned)p.sH && (unsigned)gx < (unsigned)p.sP;
+            const float* g = inb ? src + (((int64_t)gz * p.sH + gy) * p.sP + gx) : zeros16;
+            if (v < total)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                 (__attribute__((address_space(3))) void*)(dstb + 4 * vb), 16, 0, 0);
+        }
+    };
+    stage(0);
+
+    // the pixels' parameters, once per tile (lane i < 8 of wave d works out pixel (d, h0 + i)), left in LDS behind the two buffers
+    {
+        const int hl = h0 + (lane & 7);
+        const double s0 = canonical_coord(p, 0, d, hl, 0), s1 = canonical_coord(p, 1, d, hl, 0);
+        const double fzd = floor(s0), fyd = floor(s1);
+        const float fz = (float)(s0 - fzd), fy = (float)(s1 - fyd);
+        float wy[4] = {0.f, 0.f, 0.f, 0.f}, wz[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (CUBIC) {
+            if (p.flags & (1 << 18)) { cubic_weights<true>(fy, wy); cubic_weights<true>(fz, wz); }
+            else { cubic_weights<false>(fy, wy); cubic_weights<false>(fz, wz); }
+        }
+        const int rz_l = (int)fzd - HALO - oz, ry_l = (int)fyd - HALO - oy;
+        const int in_zy_l = ((s0 >= p.vlo[0]) && (s0 < p.vhi[0]) && (s1 >= p.vlo[1]) && (s1 < p.vhi[1]) && hl < p.oH && d < p.oD) ? 1 : 0;
+        if (lane < kRowPH) {
+            float* q = prm + lane * 16;
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            typedef int v4i __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<v4f*>(q) = v4f{wy[0], wy[1], wy[2], wy[3]};
+            *reinterpret_cast<v4f*>(q + 4) = v4f{wz[0], wz[1], wz[2], wz[3]};
+            *reinterpret_cast<v4f*>(q + 8) = v4f{fy, fz, 0.f, 0.f};
+            *reinterpret_cast<v4i*>(q + 12) = v4i{rz_l * Ly + ry_l, in_zy_l | ((hl < p.oH && d < p.oD) ? 2 : 0), rz_l, ry_l};
+        }
+    }
+    // the output rows of this wave's pixels through one descriptor: a lane that must not write takes an offset beyond its records
+    const int64_t orow0 = ((int64_t)min(d, p.oD - 1) * p.oH + h0) * p.oW;
+    const int orow_b = p.oW * 4;
+    __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(out + orow0), 0, (unsigned)min((int64_t)kRowPH * orow_b, (int64_t)0x7fffffff), 0x00020000);
+    constexpr int kDrop = 0x7ffffff0;             // beyond every descriptor's records: the store is dropped
+
+    bool first = true;
+    for (int r = 0; r < nruns; ++r) {
+        // run r has landed (this wave's part); the eight stores of run r - 1 were issued behind its loads and may stay in flight
+        if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(kRowPH) : "memory");
+        first = false;
+        __syncthreads();                          // ... everywhere; everyone has finished reading buffer (r + 1) & 1
+        if (r + 1 < nruns) stage(r + 1);
+        const int w = r * kRowRun + lane;
+        const double sw = (double)w + p.m[11];
+        const bool in_x = (sw >= p.vlo[2]) && (sw < p.vhi[2]);
+        const double fxd = floor(sw);
+        const float fx = (float)(sw - fxd);
+        float wx[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (FRAC && CUBIC) {
+            if (p.flags & (1 << 18)) cubic_weights<true>(fx, wx); else cubic_weights<false>(fx, wx);
+        }
+        const int x0 = (r * kRowRun + t2 - XH) & ~3;
+        int col = (int)fxd - XH - x0;
+        col = min(max(col, 0), RS - NX);
+        const unsigned lds_b = lds_byte_address(lds + (r & 1) * box_floats) + 4u * (unsigned)col;
+        const int wofs = (w < p.oW) ? 4 * w : kDrop;
+#pragma unroll
+        for (int i = 0; i < kRowPH; ++i) {
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            typedef int v4i __attribute__((ext_vector_type(4)));
+            const v4f pwy = *reinterpret_cast<const v4f*>(prm + i * 16), pwz = *reinterpret_cast<const v4f*>(prm + i * 16 + 4);
+            const v4f pf = *reinterpret_cast<const v4f*>(prm + i * 16 + 8);
+            const v4i pi = *reinterpret_cast<const v4i*>(prm + i * 16 + 12);
+            const int fl = __builtin_amdgcn_readfirstlane(pi[1]);
+            const bool inside_zy = (fl & 1) != 0, exists = (fl & 2) != 0;
+            float val = 0.f;
+            if (inside_zy) {
+                const unsigned a0 = lds_b + RSB * (unsigned)__builtin_amdgcn_readfirstlane(pi[0]);
+                float t[NT][NT];
+#pragma unroll
+                for (int c = 0; c < NT; ++c)
+#pragma unroll
+                    for (int b = 0; b < NT; ++b) {
+                        const unsigned ra = a0 + RSB * (unsigned)(c * Ly + b);
+                        auto tap = [&](int k) { return *reinterpret_cast<const __attribute__((address_space(3))) float*>((size_t)(ra + 4u * (unsigned)k)); };
+                        if constexpr (NX == 1) {
+                            t[c][b] = tap(0);
+                        } else if constexpr (NX == 2) {
+                            const float a = tap(0), bb = tap(1);
+                            t[c][b] = fmaf(fx, bb - a, a);
+                        } else {
+                            float accx = wx[0] * tap(0);
+                            accx = fmaf(wx[1], tap(1), accx);
+                            accx = fmaf(wx[2], tap(2), accx);
+                            t[c][b] = fmaf(wx[3], tap(3), accx);
+                        }
+                    }
+                if constexpr (!CUBIC) {
+                    const float y0 = fmaf(pf[0], t[0][1] - t[0][0], t[0][0]);
+                    const float y1 = fmaf(pf[0], t[1][1] - t[1][0], t[1][0]);
+                    val = fmaf(pf[1], y1 - y0, y0);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NT; ++c) {
+                        float accy = 0.f;
+#pragma unroll
+                        for (int b = 0; b < NT; ++b) accy = fmaf(pwy[b], t[c][b], accy);
+                        val = fmaf(pwz[c], accy, val);
+                    }
+                }
+            }
+            // exactly one store instruction per pixel and wave: the value, a zero, or -- where nothing may be written (a pixel or a column
+            // beyond the output, an outside voxel under keep_outside) -- a store the descriptor drops
+            const bool write_val = inside_zy && in_x;
+            const int ofs = (exists && (write_val || !keep)) ? wofs : kDrop;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, write_val ? val : 0.0f), orsrc, ofs, i * orow_b, 0);
+        }
+    }
+}
+
 typedef void (*rows_fn)(const float*, float*, const float*, const AffineParams);
 template <int PD>
 static rows_fn rows_entry_pd(int kind, int nv)
@@ -247,6 +431,18 @@ static rows_fn rows_entry_pd(int kind, int nv)
     }
 }
 static rows_fn rows_entry(int kind, int pd, int nv) { return pd == 8 ? rows_entry_pd<8>(kind, nv) : rows_entry_pd<4>(kind, nv); }
+template <int PD>
+static rows_fn rows_db_entry_pd(int kind, int nv)
+{
+    if (nv == 16) return kind == 0 ? affine_rows_db<0, PD, 16> : affine_rows_db<1, PD, 16>;
+    switch (kind) {
+        case 0: return affine_rows_db<0, PD, 18>;
+        case 1: return affine_rows_db<1, PD, 18>;
+        case 2: return affine_rows_db<2, PD, 18>;
+        default: return affine_rows_db<3, PD, 18>;
+    }
+}
+static rows_fn rows_db_entry(int kind, int pd, int nv) { return pd == 8 ? rows_db_entry_pd<8>(kind, nv) : rows_db_entry_pd<4>(kind, nv); }
 
 hipError_t init_rows_kernels()
 {
@@ -255,6 +451,8 @@ hipError_t init_rows_kernels()
             for (int nv = 16; nv <= 18; nv += 2) {
                 if (nv == 16 && kind >= 2) continue;
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rows_entry(kind, pd, nv)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return e;
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(rows_db_entry(kind, pd, nv)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 if (e != hipSuccess) return e;
             }
     return hipSuccess;
@@ -265,8 +463,13 @@ void rows_tile(int* ph, int* run) { *ph = kRowPH; *run = kRowRun; }
 // p.Lx: staged floats per row (64 or 72); flag bit 16: the axis-2 offset has a fraction (kinds 2 / 3)
 hipError_t launch_affine_rows(int interp, int pd, const float* src, float* out, const float* zeros16, const AffineParams& p, int lds_bytes, hipStream_t stream)
 {
-    const dim3 g((unsigned)((p.oW + kRowRun - 1) / kRowRun), (unsigned)((p.oH + kRowPH - 1) / kRowPH), (unsigned)((p.oD + pd - 1) / pd));
     const int kind = (interp_kind(interp) == 0 ? 0 : 1) + ((p.flags & (1 << 16)) ? 2 : 0);
+    if (p.flags & (1 << 17)) {                    // two row buffers, a workgroup walks all runs of its pixel tile (plan_rows)
+        const dim3 g2((unsigned)((p.oH + kRowPH - 1) / kRowPH), (unsigned)((p.oD + pd - 1) / pd));
+        hipLaunchKernelGGL(rows_db_entry(kind, pd, p.Lx == 64 ? 16 : 18), g2, dim3(64 * pd), lds_bytes, stream, src, out, zeros16, p);
+        return hipGetLastError();
+    }
+    const dim3 g((unsigned)((p.oW + kRowRun - 1) / kRowRun), (unsigned)((p.oH + kRowPH - 1) / kRowPH), (unsigned)((p.oD + pd - 1) / pd));
     hipLaunchKernelGGL(rows_entry(kind, pd, p.Lx == 64 ? 16 : 18), g, dim3(64 * pd), lds_bytes, stream, src, out, zeros16, p);
     return hipGetLastError();
 }

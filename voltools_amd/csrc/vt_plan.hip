@@ -1125,6 +1125,33 @@ bool plan_rows(const vt_volume* v, const double m[12], int flags, AffineParams* 
         if (ok && lds <= 64 * 1024 && lds <= v->lds_limit) pd = cand;      // (strong minification in the (d, h) plane: the general kernels serve it)
     }
     if (pd == 0) return false;
+    // Two row buffers (round 5, VT_ROWS_DB=1; 2 = on the 4 x 8 tile): a workgroup walks all runs of its pixel tile, staging run k + 1 while
+    // it computes run k.  Built because the one-run form waits half of its wave cycles (SQ_WAIT_ANY 50 %), and SLOWER: [measured, 512^3,
+    // one variant per process, tools/rows_ab.sh] trilinear 0.250 against 0.218 ms at 33 degrees (0.251 / 0.226 at 80), cubic 0.416 against
+    // 0.331 (0.413 / 0.307); on 4 x 8 tiles 0.279 / 0.443.  Two boxes are 80-108 KiB: ONE workgroup per CU, and what hides a workgroup's
+    // staging on this chip is another workgroup's compute, not its own next buffer (the same answer as for the lane-block kernel in round 3
+    // and the packed-span kernel this round).  Kept behind the knob; the conditions: the two boxes fit, the output has at least three
+    // runs, (oH / 8) x (oD / pd) workgroups fill the chip, a tile's eight output rows stay below the descriptor's 2^31 bytes.
+    bool db = false;
+    if (v->tune.rows_db != 0 && (v->oW + run - 1) / run >= 3 && (int64_t)ph * v->oW * 4 < 0x7fffffffLL) {
+        auto box_lds = [&](int cand, int* Lz, int* Ly) {
+            int LL[2];
+            for (int r = 0; r < 2; ++r) {
+                const double ext = std::fabs(m[4 * r]) * (cand - 1) + std::fabs(m[4 * r + 1]) * (ph - 1);
+                LL[r] = (int)std::floor(ext + 1.0e-8) + 3 + halo2;
+            }
+            *Lz = LL[0]; *Ly = LL[1];
+            return 2 * LL[0] * LL[1] * 4 * nv * 4 + cand * ph * 16 * 4;
+        };
+        int Lz2, Ly2;
+        for (int cand = (v->tune.rows_db == 2 ? 4 : pd); cand >= 4 && !db; cand -= 4) {
+            const int l2 = box_lds(cand, &Lz2, &Ly2);
+            const int64_t wgs = (int64_t)((v->oH + ph - 1) / ph) * ((v->oD + cand - 1) / cand);
+            if (l2 <= v->lds_limit && l2 <= 160 * 1024 && wgs >= 2 * (int64_t)v->cu_count && (v->oD + cand - 1) / cand <= 65535) {
+                db = true; pd = cand; L[0] = Lz2; L[1] = Ly2; lds = l2;
+            }
+        }
+    }
     plan_prepare(v, m, flags, p, plan);
     const int T[3] = {pd, ph, 1};
     set_tile_reach(p, m, T, 0);
@@ -1132,11 +1159,11 @@ bool plan_rows(const vt_volume* v, const double m[12], int flags, AffineParams* 
     p->psv_magic = (uint32_t)(4294967296.0 / (double)L[1]) + 1u;
     p->zoff = (int32_t)tfl;
     p->fz = 0.0f;
-    p->flags = (flags & VT_KEEP_OUTSIDE) | (frac ? (1 << 16) : 0);
+    p->flags = (flags & VT_KEEP_OUTSIDE) | (frac ? (1 << 16) : 0) | (db ? (1 << 17) : 0);
     if (v->interp == VT_BSPLINE_SIMPLE || v->interp == VT_FILT_BSPLINE_SIMPLE) p->flags |= (1 << 18);
     plan->kind = 10; plan->cfg = 0; plan->td = pd; plan->th = ph; plan->tw = run;
     plan->lds_bytes = lds;
-    plan->grid = (int)std::min<int64_t>(0x7fffffff, (int64_t)((v->oW + run - 1) / run) * ((v->oH + ph - 1) / ph) * ((v->oD + pd - 1) / pd));
+    plan->grid = (int)std::min<int64_t>(0x7fffffff, (int64_t)(db ? 1 : (v->oW + run - 1) / run) * ((v->oH + ph - 1) / ph) * ((v->oD + pd - 1) / pd));
     plan->blocks_per_cu = std::max(1, std::min(8, (160 * 1024) / std::max(1, lds)));
     return true;
 }
