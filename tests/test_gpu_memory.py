@@ -7,7 +7,7 @@ budget: `StaticVolume(..., max_resident_bytes=)` / `vt_volume_set_max_resident` 
   * `info().resident_bytes` stays inside the budget after every call, copies are evicted least recently used first, and a copy that cannot
     fit at all is not built -- the call runs on the kernel family that samples the plain layout;
   * BASELINE config #4 (1024^3 `filt_bspline`, README sweep) runs inside 8.5 GiB -- the plain copy and ONE z-convolved plane-quad copy --
-    on the marching kernel at every angle, the in-plane transposed intermediate being released once its quad form exists;
+    on the marching kernel at every angle (the transposed orientation's quad form is built straight from the plain copy);
   * with HBM filled to within 3 GiB by another allocation (no lazy copy of a 1024^3 volume fits) the same sweep still agrees with the
     oracle, on the fallback families.
 """
@@ -116,12 +116,13 @@ def test_config4_sweep_inside_8p5_gib(big):
     for ang in (46.0, 60.0, 90.0, 120.0, 134.0):
         check_window(torch, vol, sv, out, [ang], want_kernel=8)
         assert sv.info().resident_bytes <= budget, (ang, sv.info().resident_bytes)
-    # one transposed plain copy and its z-convolved quad form were built for the whole middle range, not one pair per angle
-    assert sv.info().copies_built == built_plain_side + 2, (built_plain_side, sv.info().copies_built)
+    # ONE copy was built for the whole middle range -- the transposed orientation's z-convolved quad form, straight from the plain copy
+    # (relayout_zquad_swap12; rounds 2-4 went through a volume-sized transposed plain copy) --, not one per angle
+    assert sv.info().copies_built == built_plain_side + 1, (built_plain_side, sv.info().copies_built)
     for ang in (136.0, 170.0):
         check_window(torch, vol, sv, out, [ang], want_kernel=8)
         assert sv.info().resident_bytes <= budget
-    assert sv.info().copies_built == built_plain_side + 3 and sv.info().copies_evicted >= 3
+    assert sv.info().copies_built == built_plain_side + 2 and sv.info().copies_evicted >= 2
     sv.close()
 
 
@@ -151,3 +152,37 @@ def test_config4_parity_with_hbm_nearly_full(big):
     sv.release_copies()
     check_window(torch, vol, sv, out, [30.0], want_kernel=8)
     sv.close()
+
+
+@pytest.mark.parametrize('interp', ['linear', 'filt_bspline', 'bspline_simple'])
+@pytest.mark.parametrize('shape', [(41, 70, 133), (64, 64, 64), (9, 200, 37)])
+def test_fused_transposing_relayout_builds_the_same_copy(interp, shape, monkeypatch):
+    """The plane-quad forms of the in-plane transposed orientation (in-plane maps between 45 and 135 degrees) are built straight from the
+    plain copy by `relayout_zquad_swap12` (round 5) instead of transpose02 + relayout_zquad[_fir] through an exchanged plain copy
+    (`VT_NO_FUSED_RELAYOUT=1`): the same copy, so the marching kernel returns the same bits -- integer axis-0 offsets (the z-convolved copy
+    of the cubic launches) and fractional ones (the plain plane-quad copy), ragged extents that leave partial 32 x 64 tiles and a partial
+    last quad -- and no exchanged plain copy is left resident."""
+    vol = np.random.RandomState(9).random_sample(shape).astype(np.float32)
+    c = centre(shape)
+    mats = []
+    for ang, t0 in ((80.0, 0.0), (100.0, 2.0), (60.0, 0.5)):
+        m = vt.utils.transform_matrix(rotation=(ang, 0, 0), rotation_order='sxyz', center=c)
+        m[0, 3] += t0
+        mats.append(m)
+    res = {}
+    for knob in ('0', '1'):
+        monkeypatch.setenv('VT_NO_FUSED_RELAYOUT', knob)
+        sv = vt.StaticVolume(vol, interpolation=interp, device='gpu:0')
+        plain = sv.info().resident_bytes
+        outs = []
+        for m in mats:
+            outs.append(sv.affine(m, _flags=_native.FORCE_TILED))
+            assert sv.info().last_kernel == 8, (interp, shape, knob)
+        res[knob] = (outs, sv.info().resident_bytes - plain, sv.info().copies_built)
+        sv.close()
+    for a, b in zip(res['0'][0], res['1'][0]):
+        assert np.array_equal(a, b)
+    assert res['0'][1] < res['1'][1] and res['0'][2] < res['1'][2]          # one volume-sized buffer and one build less
+    tol = {'linear': 1e-6, 'filt_bspline': 3e-6, 'bspline_simple': 1e-6}[interp]
+    for m, a in zip(mats, res['0'][0]):
+        assert np.abs(a - oracle.affine(vol, m, interp)).max() <= tol

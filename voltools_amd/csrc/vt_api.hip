@@ -867,7 +867,10 @@ int ensure_secondary_copy(vt_volume* v, const TilePlan& plan, const AffineParams
     // The exchanged plain-layout copy of the orientation: read by the launch itself (kinds that sample the plain layout) or by the relayout
     // that builds the missing plane-quad form.  Built here and not when the orientation is chosen: under a budget it is the first copy
     // evicted once its quad form exists, and a sweep must not rebuild it on every call.
-    if (ori.plain_id >= 0) {
+    // (Round 5: the plane-quad forms of the in-plane transposed orientation come straight from the handle's own plain copy --
+    // relayout_zquad_swap12 -- when that exchanged copy does not exist yet: nothing else reads it on this path.)
+    const bool fused_swap12 = plan.kind == 8 && ori.plain_id == kCopyR && !v->d_src_r && !v->tune.no_fused_relayout;
+    if (ori.plain_id >= 0 && !fused_swap12) {
         if (ensure_lazy_plain(v, ori.plain_id)) return 1;
         ori.src_plain = *lazy_slot(v, ori.plain_id);
     }
@@ -881,7 +884,7 @@ int ensure_secondary_copy(vt_volume* v, const TilePlan& plan, const AffineParams
     int* const retry = (plan.kind == 8) ? &v->copy_retry_in[ori.quad_idx + (zfir ? 4 : 0)] : nullptr;
     if (retry && *retry > 0) { --*retry; return 1; }
     hipError_t e = hipSuccess;
-    if (id >= 0) e = alloc_lazy(v, id, bytes, id, ori.plain_id, ori.plain_id);
+    if (id >= 0) e = alloc_lazy(v, id, bytes, id, fused_swap12 ? -1 : ori.plain_id, fused_swap12 ? -1 : ori.plain_id);
     else e = hipMalloc(reinterpret_cast<void**>(slot), bytes);
     if (e != hipSuccess) {
         (void)hipGetLastError();              // no room for another copy of the volume: a family that reads the plain layout serves the call
@@ -890,9 +893,11 @@ int ensure_secondary_copy(vt_volume* v, const TilePlan& plan, const AffineParams
         return 1;
     }
     lazy_build_begin(v);
-    e = hipMemsetAsync(*slot, 0, bytes, v->stream);       // positions beyond the row's width stay zero
+    if (plan.kind != 8) e = hipMemsetAsync(*slot, 0, bytes, v->stream);       // positions beyond the row's width stay zero (the plane-quad relayouts write them themselves)
     if (e == hipSuccess) {
-        if (zfir)
+        if (fused_swap12)
+            e = launch_relayout_zquad_swap12(v->d_src, *slot, v->D, v->H, v->W, v->P, p.sPq, zfir, (p.flags & (1 << 18)) != 0, v->stream);
+        else if (zfir)
             e = launch_relayout_zquad_fir(ori.src_plain, *slot, ori.srcD, ori.srcH, ori.rowW, ori.rowP, p.sPq, (p.flags & (1 << 18)) != 0, v->stream);
         else if (plan.kind == 8)
             e = launch_relayout_zquad(ori.src_plain, *slot, ori.srcD, ori.srcH, ori.rowW, ori.rowP, p.sPq, v->stream);
@@ -913,7 +918,7 @@ int ensure_secondary_copy(vt_volume* v, const TilePlan& plan, const AffineParams
     lazy_build_end(v);
     if (zfir) v->quade_bytes[ori.quad_idx] = bytes;
     else if (plan.kind == 8) v->quad_bytes[ori.quad_idx] = bytes;
-    if (id >= 0) release_transient(v, ori.plain_id, id);             // (lazy_build_end has waited for the relayout: its source may go)
+    if (id >= 0) release_transient(v, fused_swap12 ? -1 : ori.plain_id, id);             // (lazy_build_end has waited for the relayout: its source may go)
     if (std::getenv("VT_DEBUG_ALLOC")) std::fprintf(stderr, "[vt] secondary copy kind %d orientation %d at %p, %zu bytes (plain source %p)\n", plan.kind, ori.quad_idx, (void*)*slot, bytes, (const void*)ori.src_plain);
     if (zfir) v->quade_bytes[ori.quad_idx] = bytes;
     else if (plan.kind == 8) v->quad_bytes[ori.quad_idx] = bytes;

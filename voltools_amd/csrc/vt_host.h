@@ -36,6 +36,7 @@ struct Tuning {
     int quad_zid = 1;              // VT_QUAD_ZID=0: trilinear launches with fz == 0 keep the two-plane kernel (round-3 A/B)
     int reorient = 4;              // VT_REORIENT: general matrices sample the resident copy whose rows follow the output's w axis, built at the n-th request (0 = never)
     int rows_pd = 8;               // VT_ROWS_PD=4: the row kernel's pixel tile is 4 x 8 (four waves) instead of 8 x 8
+    int no_fused_relayout = 0;     // VT_NO_FUSED_RELAYOUT=1: the plane-quad forms of the in-plane transposed orientation through an exchanged plain copy (rounds 2-4) instead of relayout_zquad_swap12
     int rows_db = 0;               // VT_ROWS_DB: 0 = one run per workgroup (the default: faster), 1 = the row kernel walks a tile's runs with two row buffers where they fit, 2 = the same on the 4 x 8 tile
     int rows = 1;                  // VT_ROWS=0: maps that leave axis 2 alone take the axis-exchange path instead of the row kernel (kind 10)
     int quad_zfir = 1;             // VT_QUAD_ZFIR=0: cubic launches with fz == 0 keep the four-plane kernel (round-4 A/B: the z-convolved copy)
@@ -87,6 +88,7 @@ struct Tuning {
         rows = num("VT_ROWS", 1);
         rows_pd = num("VT_ROWS_PD", 8);
         rows_db = num("VT_ROWS_DB", 0);
+        no_fused_relayout = num("VT_NO_FUSED_RELAYOUT", 0);
         reorient = num("VT_REORIENT", 4);
         no_proj_cache = std::getenv("VT_NO_PROJ_CACHE") != nullptr;
         zid_dch = num("VT_ZID_DCH", 0);

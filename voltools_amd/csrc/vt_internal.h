@@ -224,6 +224,8 @@ hipError_t init_rows_kernels();
 void rows_tile(int* ph, int* run);
 hipError_t launch_affine_rows(int interp, int pd, const float* src, float* out, const float* zeros16, const AffineParams& p, int lds_bytes, hipStream_t stream);
 hipError_t launch_relayout_zquad_fir(const float* src, float* dst, int D, int H, int W, int P, int Pq, bool simple, hipStream_t stream);
+// the same two forms of the in-plane transposed orientation, straight from the plain copy (no exchanged plain copy in between)
+hipError_t launch_relayout_zquad_swap12(const float* src, float* dst, int D, int H, int W, int P, int Pq, bool fir, bool simple, hipStream_t stream);
 hipError_t launch_affine_quad(int cfg, int interp, const float* srcq, float* out, const AffineParams& p,
                               int grid, int lds_bytes, hipStream_t stream);
 // lane-block kernel for general matrices (vt_kernels_block.hip)

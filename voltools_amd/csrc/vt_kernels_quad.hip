@@ -55,7 +55,11 @@ __global__ __launch_bounds__(256) void relayout_zquad(const float* __restrict__ 
     const int x = blockIdx.x * 256 + threadIdx.x;
     const int y = blockIdx.y;
     const int qq = blockIdx.z;
-    if (x >= W) return;
+    if (4 * x >= Pq) return;
+    if (x >= W) {                                  // the row's pad positions: written here, the buffer is not cleared beforehand (round 5)
+        *reinterpret_cast<v4f*>(dst + ((int64_t)qq * H + y) * Pq + 4 * (int64_t)x) = v4f{0.f, 0.f, 0.f, 0.f};
+        return;
+    }
     const int z0 = 4 * qq;
     const int64_t plane = (int64_t)H * P;
     const float* s = src + ((int64_t)z0 * H + y) * P + x;
@@ -69,8 +73,8 @@ __global__ __launch_bounds__(256) void relayout_zquad(const float* __restrict__ 
 
 hipError_t launch_relayout_zquad(const float* src, float* dst, int D, int H, int W, int P, int Pq, hipStream_t stream)
 {
-    const dim3 grid((W + 255) / 256, H, (D + 3) / 4);
-    if (grid.y > 65535 || grid.z > 65535) return hipErrorInvalidValue;
+    const dim3 grid((Pq / 4 + 255) / 256, H, (D + 3) / 4);
+    if (grid.y > 65535 || grid.z > 65535 || (Pq & 3) || Pq < 4 * W) return hipErrorInvalidValue;
     hipLaunchKernelGGL(relayout_zquad, grid, dim3(256), 0, stream, src, dst, D, H, W, P, Pq);
     return hipGetLastError();
 }
@@ -87,7 +91,11 @@ __global__ __launch_bounds__(256) void relayout_zquad_fir(const float* __restric
     const int x = blockIdx.x * 256 + threadIdx.x;
     const int y = blockIdx.y;
     const int qq = blockIdx.z;
-    if (x >= W) return;
+    if (4 * x >= Pq) return;
+    if (x >= W) {
+        *reinterpret_cast<v4f*>(dst + ((int64_t)qq * H + y) * Pq + 4 * (int64_t)x) = v4f{0.f, 0.f, 0.f, 0.f};
+        return;
+    }
     const int z0 = 4 * qq;
     const int64_t plane = (int64_t)H * P;
     const float* s = src + ((int64_t)z0 * H + y) * P + x;
@@ -110,9 +118,76 @@ __global__ __launch_bounds__(256) void relayout_zquad_fir(const float* __restric
 
 hipError_t launch_relayout_zquad_fir(const float* src, float* dst, int D, int H, int W, int P, int Pq, bool simple, hipStream_t stream)
 {
-    const dim3 grid((W + 255) / 256, H, (D + 3) / 4);
-    if (grid.y > 65535 || grid.z > 65535) return hipErrorInvalidValue;
+    const dim3 grid((Pq / 4 + 255) / 256, H, (D + 3) / 4);
+    if (grid.y > 65535 || grid.z > 65535 || (Pq & 3) || Pq < 4 * W) return hipErrorInvalidValue;
     hipLaunchKernelGGL(relayout_zquad_fir, grid, dim3(256), 0, stream, src, dst, D, H, W, P, Pq, simple ? 1 : 0);
+    return hipGetLastError();
+}
+
+// Round 5: the plane-quad copy (FIR: of the z-convolved volume) of the IN-PLANE TRANSPOSED orientation straight from the handle's plain
+// copy -- dst row (quad, x) holds source column x: element (z, y, x) at 4y + (z & 3) -- instead of transpose02 into an exchanged plain copy
+// and relayout_zquad[_fir] from there.  Same values bit for bit (the FIR sums the same three planes in the same association), one read and
+// one write of the volume instead of two, and no volume-sized temporary: under a resident budget (vt_volume_set_max_resident) a README sweep
+// rebuilds this copy once per half turn, and the temporary's hipMalloc / hipFree cost as much as its kernel.
+// A workgroup transposes a 32 (y) x 64 (x) tile of one quad through LDS: reads coalesced along x, writes 512 contiguous bytes per half wave
+// along y.  Rows are padded by one vector: lane y reads bank group 4y mod 64, no conflict among the 16 lanes of a b128 pass.
+constexpr int kSwapTY = 32, kSwapTX = 64;
+template <bool FIR>
+__global__ __launch_bounds__(256) void relayout_zquad_swap12(const float* __restrict__ src, float* __restrict__ dst,
+                                                              int D, int H, int W, int P, int Pq, int simple)
+{
+    __shared__ v4f tile[kSwapTY * (kSwapTX + 1)];
+    const int x0 = blockIdx.x * kSwapTX, y0 = blockIdx.y * kSwapTY, qq = blockIdx.z;
+    const int z0 = 4 * qq;
+    const int64_t plane = (int64_t)H * P;
+    float wz[4];
+    if (simple) cubic_weights<true>(0.0f, wz); else cubic_weights<false>(0.0f, wz);
+    const int xl = threadIdx.x & (kSwapTX - 1);
+#pragma unroll
+    for (int i = 0; i < kSwapTY / 4; ++i) {
+        const int yl = (threadIdx.x >> 6) + 4 * i;
+        const int x = x0 + xl, y = y0 + yl;
+        v4f v = {0.f, 0.f, 0.f, 0.f};
+        if (x < W && y < H) {
+            const float* s = src + ((int64_t)z0 * H + y) * P + x;
+            if (FIR) {
+                float c[6];                           // planes z0 - 1 .. z0 + 4
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const int z = z0 - 1 + k;
+                    c[k] = (z >= 0 && z < D) ? s[(int64_t)(k - 1) * plane] : 0.0f;
+                }
+                v.x = fmaf(wz[2], c[2], fmaf(wz[1], c[1], wz[0] * c[0]));
+                v.y = (z0 + 1 < D) ? fmaf(wz[2], c[3], fmaf(wz[1], c[2], wz[0] * c[1])) : 0.0f;
+                v.z = (z0 + 2 < D) ? fmaf(wz[2], c[4], fmaf(wz[1], c[3], wz[0] * c[2])) : 0.0f;
+                v.w = (z0 + 3 < D) ? fmaf(wz[2], c[5], fmaf(wz[1], c[4], wz[0] * c[3])) : 0.0f;
+            } else {
+                v.x = s[0];
+                v.y = (z0 + 1 < D) ? s[plane] : 0.0f;
+                v.z = (z0 + 2 < D) ? s[2 * plane] : 0.0f;
+                v.w = (z0 + 3 < D) ? s[3 * plane] : 0.0f;
+            }
+        }
+        tile[yl * (kSwapTX + 1) + xl] = v;
+    }
+    __syncthreads();
+    const int yl = threadIdx.x & (kSwapTY - 1);
+#pragma unroll
+    for (int i = 0; i < kSwapTX / 8; ++i) {
+        const int xr = (threadIdx.x >> 5) + 8 * i;
+        const int x = x0 + xr, y = y0 + yl;
+        if (x < W && 4 * y < Pq)                      // y >= H: the row's pad positions (the tile holds zeros there)
+            *reinterpret_cast<v4f*>(dst + ((int64_t)qq * W + x) * Pq + 4 * (int64_t)y) = tile[yl * (kSwapTX + 1) + xr];
+    }
+}
+
+// D, H, W, P: the handle's plain copy; the copy's rows are the W source columns, Pq floats each (>= 4 * H)
+hipError_t launch_relayout_zquad_swap12(const float* src, float* dst, int D, int H, int W, int P, int Pq, bool fir, bool simple, hipStream_t stream)
+{
+    const dim3 grid((W + kSwapTX - 1) / kSwapTX, (Pq / 4 + kSwapTY - 1) / kSwapTY, (D + 3) / 4);
+    if (grid.y > 65535 || grid.z > 65535 || (Pq & 3) || Pq < 4 * H) return hipErrorInvalidValue;
+    if (fir) hipLaunchKernelGGL(relayout_zquad_swap12<true>, grid, dim3(256), 0, stream, src, dst, D, H, W, P, Pq, simple ? 1 : 0);
+    else hipLaunchKernelGGL(relayout_zquad_swap12<false>, grid, dim3(256), 0, stream, src, dst, D, H, W, P, Pq, 0);
     return hipGetLastError();
 }
 
