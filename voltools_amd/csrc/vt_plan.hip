@@ -387,7 +387,10 @@ bool plan_quad(PlanCtx& c)
     // 512^3 (variants in one process): 0.1961 at 24, 0.1979 at 16, 0.1992 at 32 -- within the handle-to-handle spread; decided per process below
     // (KIND 4, cubic on the z-convolved copy, keeps the cubic depth: its set-up -- the row-span table -- is the expensive one.  512^3 filt_bspline, one
     // process per variant: 0.2495 ms at 16 planes, 0.2047 at 32, 0.1975 at 64, 0.2103 at 128; the four-plane kernel 0.2046)
-    if (zfir_on && (int64_t)v->H * v->W > 512 * 512) target_dch = 32;      // 1024^3 filt_bspline: 1.563 ms at 64 planes, 1.527 at 32 (four-plane kernel: 1.594)
+    // Round 5 re-check on the final kernel (tile origin in scalar registers, cheaper set-up), one process per variant, 60 angles, three alternations
+    // (profiles/r05_headline_chunk_depth.txt): 512^3 0.2064 ms at 16 planes, 0.1905 at 24, 0.1873 at 32, 0.1869 at 40, 0.1880 at 48, 0.1923 at 64 --
+    // 32 planes at every size now (1024^3 filt_bspline: 1.563 ms at 64 planes, 1.527 at 32; four-plane kernel: 1.594)
+    if (zfir_on) target_dch = 32;
     if (zid) target_dch = 16;             // 512^3, one process per variant (profiles/r03_process_ab.txt): 0.1896 ms at 16, 0.1911 at 20, 0.1922 at 24, 0.1953 at 32
     if (one_plane && v->tune.zid_dch > 0) target_dch = v->tune.zid_dch;
     if (v->tune.dch > 0) target_dch = std::max(4, v->tune.dch);
