@@ -289,12 +289,27 @@ namespace {
 // Host <-> device copies of caller-owned (pageable) numpy buffers.  Pageable copies run at ~10 GB/s through the
 // runtime's staging path; pinning the caller's buffer in place for the duration of the copy lets the DMA engines run at
 // PCIe rate.  Falls back to the plain copy when registration is refused (VT_NO_PIN=1 disables it).
+//
+// What must never happen (round 5, the cause of the `Memory access fault by GPU` on a host address that rounds 1, 2 and 4 each met and
+// explained differently; found with VT_DEBUG_PIN=1, profiles/r05_pin_trace.txt): a registration of ours that OVERLAPS a pin of the
+// runtime's own.  The runtime serves a pageable transfer of more than 1 MiB by pinning the caller's pages in place, and keeps the last few
+// such pins (a cache keyed by address and size, released first-in first-out or when the queue dies), long after the transfer and after the
+// caller's array has been freed.  When the heap hands the same addresses to the next, larger array and that array's interior is
+// registered here, two pinned objects cover the same pages: the registration succeeds, the copy resolves its host address to the OLD,
+// smaller object and runs off its end -- or the old pin is dropped from the cache under the copy -- and the GPU faults inside a range that
+// was registered "ok" a moment ago.  (The trace: four 1.3 MB results at 0x..3d8eef90 .. 0x..3dcbd840, then a 32 MB input at 0x..3d8eef90,
+// interior [0x..3da00000, 0x..3f600000) registered ok, fault at 0x..3f3c7000.)  Two rules follow:
+//   1. no transfer issued here is ever pinned by the runtime: every pageable piece goes in slices of kSlice = 512 KiB, half the runtime's
+//      threshold, i.e. through its staging buffers (1-8 MiB arrays lose the pinned rate they used to get: 0.3 ms on 4 MiB);
+//   2. nothing is registered over a range in which the runtime already knows a pinned object (somebody else's pageable transfer, a caller's
+//      own registration): the range is probed every kSlice bytes -- a runtime pin is longer than 1 MiB, so none can hide between two probes.
 struct PinnedScope {
     void* ptr = nullptr;
     bool pinned = false;
+    static bool trace() { static const bool t = std::getenv("VT_DEBUG_PIN") != nullptr; return t; }
     // Memory the runtime already knows as pinned host memory (the Python layer's pooled result buffers, a caller's own
-    // hipHostMalloc / hipHostRegister): registering the same range a second time SUCCEEDS, and the matching unregister at the
-    // end of the scope then strips the owner's registration ([measured, round 2] the pool's later
+    // hipHostMalloc / hipHostRegister, the runtime's own pins): registering the same range a second time SUCCEEDS, and the matching
+    // unregister at the end of the scope then strips the owner's registration ([measured, round 2] the pool's later
     // hipHostUnregister failed with "pointer does not correspond to a registered memory region", and the sticky error
     // failed the next kernel-launch check).
     static bool already_registered(const void* p)
@@ -304,50 +319,84 @@ struct PinnedScope {
         if (e != hipSuccess) { (void)hipGetLastError(); return false; }
         return attr.type == hipMemoryTypeHost;
     }
-    // Round 5: only WHOLE 2 MiB units that lie INSIDE the caller's array are registered, and the copies below are cut at the ends of that
-    // interior.  Registration pins and maps pages at the host's own virtual address, and releasing any pinned range takes the mapping
-    // units it touches out of the GPU's page table -- under whatever else is registered in the same unit (the Python layer's pooled
-    // result buffers, the runtime's own temporary pins).  The unit is the host's transparent huge page, 2 MiB, not the 4 KiB page round
-    // 4 still rounded to here (the `Memory access fault by GPU` on a host address of round 4's suite runs): a range
-    // rounded OUTWARD to 4 KiB shares its first and last 2 MiB unit with the caller's neighbouring heap objects, one rounded outward to
-    // 2 MiB would pin memory that is not the caller's.  The interior shares no unit with anything; the ragged head and tail of the array
-    // (< 2 MiB each) travel as ordinary pageable copies through the runtime's staging buffers.
+    static bool any_registered(uintptr_t a, uintptr_t b)
+    {
+        for (uintptr_t x = a; x < b; x += kSlice)
+            if (already_registered(reinterpret_cast<const void*>(x))) return true;
+        return b > a && already_registered(reinterpret_cast<const void*>(b - 1));
+    }
+    // Only WHOLE 2 MiB units that lie INSIDE the caller's array are registered, and the copies below are cut at the ends of that
+    // interior: a range rounded outward would pin memory that is not the caller's (its heap neighbours'), and the host's transparent huge
+    // pages make 2 MiB the unit in which a pin can come and go without touching anything else.  The ragged head and tail of the array
+    // (< 2 MiB each) travel as pageable slices.
     char* lo = nullptr;               // the registered interior [lo, hi) of the caller's range
     char* hi = nullptr;
+    mutable hipStream_t last_stream = nullptr;
+    mutable bool used_stream = false;
     static constexpr uintptr_t kUnit = 2u << 20;
+    static constexpr size_t kSlice = 512u << 10;
     PinnedScope(const void* p, size_t bytes)
     {
         static const bool off = std::getenv("VT_NO_PIN") != nullptr;
-        if (off || !p || bytes < (8u << 20) || already_registered(p)) return;
+        if (trace() && p) std::fprintf(stderr, "[vt pin] scope %p + %zu\n", p, bytes);
+        if (off || !p || bytes < (8u << 20)) return;
         const uintptr_t a0 = (reinterpret_cast<uintptr_t>(p) + kUnit - 1) & ~(kUnit - 1);
         const uintptr_t a1 = (reinterpret_cast<uintptr_t>(p) + bytes) & ~(kUnit - 1);
-        if (a1 <= a0 || a1 - a0 < (4u << 20) || already_registered(reinterpret_cast<const void*>(a0))) return;
+        if (a1 <= a0 || a1 - a0 < (4u << 20)) return;
+        // (the head and tail are probed too: a runtime pin that starts in the head reaches into the interior)
+        if (any_registered(reinterpret_cast<uintptr_t>(p), reinterpret_cast<uintptr_t>(p) + bytes)) {
+            if (trace()) std::fprintf(stderr, "[vt pin] %p + %zu overlaps memory the runtime has pinned already: not registered\n", p, bytes);
+            return;
+        }
         ptr = reinterpret_cast<void*>(a0);
         pinned = hipHostRegister(ptr, a1 - a0, hipHostRegisterDefault) == hipSuccess;
+        if (trace()) std::fprintf(stderr, "[vt pin] registered [%p, %p): %s\n", ptr, (void*)a1, pinned ? "ok" : "refused");
         if (!pinned) { (void)hipGetLastError(); return; }
         lo = reinterpret_cast<char*>(a0);
         hi = reinterpret_cast<char*>(a1);
+    }
+    // is [h, h + n) memory the runtime treats as pinned (our interior, or a range somebody registered: the pool's buffers)?
+    bool is_pinned_range(const char* h, size_t n) const
+    {
+        if (pinned && h >= lo && h + n <= hi) return true;
+        return already_registered(h);
+    }
+    // one pageable piece, in slices the runtime stages (rule 1)
+    static hipError_t sliced(char* dst, const char* src, size_t bytes, hipMemcpyKind kind, hipStream_t st)
+    {
+        for (size_t off = 0; off < bytes; off += kSlice) {
+            const hipError_t e = hipMemcpyAsync(dst + off, src + off, std::min(kSlice, bytes - off), kind, st);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
     }
     // A copy between device memory and a part of the caller's range, cut so that every piece lies either wholly inside the registered
     // interior or wholly outside it: the runtime decides "pinned or pageable" from a transfer's first host byte, and a pinned transfer
     // that runs past the end of the registration would let the DMA engine read unmapped pages.  `host` may be the source or the target.
     hipError_t copy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t st) const
     {
-        if (!pinned || bytes == 0) return hipMemcpyAsync(dst, src, bytes, kind, st);
+        if (bytes == 0) return hipSuccess;
+        last_stream = st; used_stream = true;
         const bool h2d = kind == hipMemcpyHostToDevice;
         const char* const h0 = h2d ? static_cast<const char*>(src) : static_cast<const char*>(dst);
         const char* const h1 = h0 + bytes;
+        if (!pinned) {
+            // memory that is registered as a whole (the Python layer's pooled result buffers, a caller's own pinned array): one transfer
+            if (already_registered(h0) && already_registered(h1 - 1)) return hipMemcpyAsync(dst, src, bytes, kind, st);
+            return sliced(static_cast<char*>(dst), static_cast<const char*>(src), bytes, kind, st);
+        }
         const char* cuts[4] = {h0, std::min(std::max(h0, (const char*)lo), h1), std::min(std::max(h0, (const char*)hi), h1), h1};
         for (int i = 0; i < 3; ++i) {
             const size_t off = (size_t)(cuts[i] - h0), len = (size_t)(cuts[i + 1] - cuts[i]);
             if (!len) continue;
-            const hipError_t e = hipMemcpyAsync(static_cast<char*>(dst) + off, static_cast<const char*>(src) + off, len, kind, st);
+            const hipError_t e = (i == 1) ? hipMemcpyAsync(static_cast<char*>(dst) + off, static_cast<const char*>(src) + off, len, kind, st)
+                                          : sliced(static_cast<char*>(dst) + off, static_cast<const char*>(src) + off, len, kind, st);
             if (e != hipSuccess) return e;
         }
         return hipSuccess;
     }
-    // ... and the pitched form: `rows` dense host rows of `row_bytes` to / from device rows `dpitch` apart.  Whole rows inside / outside
-    // the interior go as 2-D copies, a row that straddles one of its ends is cut there.
+    // ... and the pitched form: `rows` dense host rows of `row_bytes` to / from device rows `dpitch` apart.  Whole rows inside the interior
+    // go as one 2-D copy, rows outside it in blocks of at most kSlice bytes, a row that straddles one of its ends is cut there.
     hipError_t copy2d(void* dev, size_t dpitch, const void* host, size_t row_bytes, size_t rows, bool h2d, hipStream_t st) const
     {
         const hipMemcpyKind kind = h2d ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
@@ -358,27 +407,54 @@ struct PinnedScope {
             return h2d ? hipMemcpy2DAsync(d, dpitch, h, row_bytes, row_bytes, r1 - r0, kind, st)
                        : hipMemcpy2DAsync(const_cast<char*>(h), row_bytes, d, dpitch, row_bytes, r1 - r0, kind, st);
         };
-        auto one_row = [&](size_t r) -> hipError_t {          // through copy(): cut at the interior's ends
+        auto one_row = [&](size_t r) -> hipError_t {          // through copy(): cut at the interior's ends, sliced where pageable
             char* d = static_cast<char*>(dev) + r * dpitch;
             const char* h = static_cast<const char*>(host) + r * row_bytes;
             return h2d ? copy(d, h, row_bytes, kind, st) : copy(const_cast<char*>(h), d, row_bytes, kind, st);
         };
-        if (!pinned || rows == 0 || row_bytes == 0) return block(0, rows);
+        auto pageable = [&](size_t r0, size_t r1) -> hipError_t {       // rows outside the interior: blocks the runtime stages (rule 1)
+            if (r1 <= r0) return hipSuccess;
+            if (row_bytes > kSlice) {
+                for (size_t r = r0; r < r1; ++r) { const hipError_t e = one_row(r); if (e != hipSuccess) return e; }
+                return hipSuccess;
+            }
+            const size_t step = std::max<size_t>(1, kSlice / row_bytes);
+            for (size_t r = r0; r < r1; r += step) { const hipError_t e = block(r, std::min(r + step, r1)); if (e != hipSuccess) return e; }
+            return hipSuccess;
+        };
+        if (rows == 0 || row_bytes == 0) return hipSuccess;
+        last_stream = st; used_stream = true;
         const char* const h0 = static_cast<const char*>(host);
-        auto row_of = [&](const char* a) { return a <= h0 ? (size_t)0 : std::min(rows, (size_t)(a - h0) / row_bytes); };   // row that holds byte a
+        if (!pinned) {
+            if (already_registered(h0) && already_registered(h0 + rows * row_bytes - 1)) return block(0, rows);
+            return pageable(0, rows);
+        }
+        auto row_of = [&](const char* a) -> size_t {          // row that holds byte a
+            if (a <= h0) return 0;
+            return std::min(rows, (size_t)(a - h0) / row_bytes);
+        };
         // rows [0, ra): wholly below lo; row ra may straddle lo; rows (ra', rb): wholly inside; row rb may straddle hi; rows beyond: outside
         const size_t ra = row_of(lo), rb = row_of(hi);
         const bool cut_a = ra < rows && h0 + ra * row_bytes < lo;                              // row ra starts below lo
         const size_t in0 = cut_a ? ra + 1 : ra;
         const bool cut_b = rb < rows && rb >= in0 && h0 + rb * row_bytes < hi;                 // row rb starts inside and ends beyond hi
-        hipError_t e = block(0, ra);
+        hipError_t e = pageable(0, ra);
         if (e == hipSuccess && cut_a) e = one_row(ra);
         if (e == hipSuccess) e = block(in0, std::max(in0, rb));
         if (e == hipSuccess && cut_b) e = one_row(rb);
-        if (e == hipSuccess) e = block(std::max(in0, cut_b ? rb + 1 : rb), rows);
+        if (e == hipSuccess) e = pageable(std::max(in0, cut_b ? rb + 1 : rb), rows);
         return e;
     }
-    ~PinnedScope() { if (pinned && hipHostUnregister(ptr) != hipSuccess) (void)hipGetLastError(); }
+    ~PinnedScope()
+    {
+        if (!pinned) return;
+        // (no transfer may still be reading or writing the range when its mapping goes: the regular paths have waited already, an error
+        //  return in between has not)
+        if (used_stream) (void)hipStreamSynchronize(last_stream);
+        const hipError_t e = hipHostUnregister(ptr);
+        if (trace()) std::fprintf(stderr, "[vt pin] released [%p, %p): %s\n", ptr, (void*)hi, e == hipSuccess ? "ok" : hipGetErrorString(e));
+        if (e != hipSuccess) (void)hipGetLastError();
+    }
 };
 
 // Run the three passes X, Y, Z (reference order, transforms.py:305-307) on d_a, using d_b as the
@@ -940,6 +1016,21 @@ int launch_planned(vt_volume* v, const TilePlan& plan, const AffineParams& p, co
         // last to first -- the control, which measures like 0.)
         AffineParams q = p;
         if (v->tune.quad_pingpong == 2 || (v->tune.quad_pingpong == 1 && ((v->launch_no++) & 1))) q.flags |= (1 << 20);
+        // Tile table (round 5): the in-plane set-up of every tile once per launch, in a one-layer pass in front of the real launch, instead of
+        // once per chunk layer.  For the kinds whose set-up weighs most against a short chunk (integer axis-0 offsets: KIND 3 / 4) from three
+        // layers on; VT_QUAD_TABLE=0 never, 1 for every plane-quad launch on the 2-D grid.  The buffer (16 * NREC4 bytes per thread and
+        // tile: 32 bytes per in-plane output pixel for the headline kernel) belongs to the handle and only grows.
+        const bool zid_kind = (q.flags & ((1 << 25) | (1 << 19))) != 0;
+        const int tq = v->tune.quad_table;
+        if ((q.flags & (1 << 29)) && tq != 0 && (tq > 0 || (zid_kind && q.nTd >= 3))) {
+            const size_t need = quad_table_bytes(plan.cfg, v->interp, zid_kind, (int64_t)q.nTh * q.nTw);
+            if (v->tile_tbl_bytes < need) {
+                if (v->d_tile_tbl) { (void)hipStreamSynchronize(v->stream); (void)hipFree(v->d_tile_tbl); v->d_tile_tbl = nullptr; v->tile_tbl_bytes = 0; }
+                if (hipMalloc(reinterpret_cast<void**>(&v->d_tile_tbl), need) == hipSuccess) v->tile_tbl_bytes = need;
+                else { (void)hipGetLastError(); v->d_tile_tbl = nullptr; }
+            }
+            if (v->d_tile_tbl) { q.tile_tbl = v->d_tile_tbl; q.tbl_mode = 2; }
+        }
         VT_HIP(launch_affine_quad(plan.cfg, v->interp, srcq, d_out, q, plan.grid, plan.lds_bytes, v->stream));
 #ifdef VT_LEGACY
     } else if (plan.kind == 5) {
@@ -1043,10 +1134,11 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
 
     float* d_out = out;
     const bool host_out = !(flags & VT_OUT_DEVICE);
+    PinnedScope pin(host_out ? out : nullptr, host_out ? n_out * sizeof(float) : 0);       // the caller's array: in (keep_outside) and out
     if (host_out) {
         if ((rc = host_output_buffer(v, n_out, &d_out))) return rc;
         if (flags & VT_KEEP_OUTSIDE)   // caller's stale values must survive: bring them in first
-            VT_HIP(hipMemcpyAsync(d_out, out, n_out * sizeof(float), hipMemcpyHostToDevice, v->stream));
+            VT_HIP(pin.copy(d_out, out, n_out * sizeof(float), hipMemcpyHostToDevice, v->stream));
     }
     float* const d_final = d_out;
     if (ori.xswap) d_out = v->d_tmp_x;            // the kernels write the exchanged result [w][h][d]
@@ -1055,7 +1147,6 @@ int do_affine(vt_volume* v, const double m4x4[16], float* out, int flags)
         VT_HIP(launch_transpose02(v->d_tmp_x, d_final, v->oW, v->oH, v->oD, (int64_t)v->oH * v->oD, v->oD,
                                   (int64_t)v->oH * v->oW, v->oW, v->stream));
     if (host_out) {
-        PinnedScope pin(out, n_out * sizeof(float));
         VT_HIP(pin.copy(out, d_final, n_out * sizeof(float), hipMemcpyDeviceToHost, v->stream));
         VT_HIP(hipStreamSynchronize(v->stream));
     }
@@ -1456,9 +1547,12 @@ int do_affine_batch(vt_volume* v, int n, const double* m4x4s, float* out, int fl
         VT_HIP(hipMalloc(reinterpret_cast<void**>(&v->d_batch_m), ms.size() * sizeof(double)));
         v->batch_m_cap = ms.size();
     }
-    VT_HIP(hipMemcpyAsync(v->d_batch_m, ms.data(), ms.size() * sizeof(double), hipMemcpyHostToDevice, v->stream));
+    // (pageable host memory never travels in pieces the runtime would pin in place: PinnedScope, rule 1)
+    VT_HIP(PinnedScope::sliced(reinterpret_cast<char*>(v->d_batch_m), reinterpret_cast<const char*>(ms.data()), ms.size() * sizeof(double),
+                               hipMemcpyHostToDevice, v->stream));
     float* d_out = out;
     const size_t total = n_out * (size_t)n;
+    PinnedScope pin(host_out ? out : nullptr, host_out ? total * sizeof(float) : 0);
     if (host_out) {
         if (v->scratch_elems < total) {
             if (v->d_scratch_out) { cached_free(v->dev, v->d_scratch_out, v->scratch_elems * sizeof(float)); v->d_scratch_out = nullptr; v->scratch_elems = 0; }
@@ -1466,7 +1560,7 @@ int do_affine_batch(vt_volume* v, int n, const double* m4x4s, float* out, int fl
             v->scratch_elems = total;
         }
         d_out = v->d_scratch_out;
-        if (flags & VT_KEEP_OUTSIDE) VT_HIP(hipMemcpyAsync(d_out, out, total * sizeof(float), hipMemcpyHostToDevice, v->stream));
+        if (flags & VT_KEEP_OUTSIDE) VT_HIP(pin.copy(d_out, out, total * sizeof(float), hipMemcpyHostToDevice, v->stream));
     }
     for (int first = 0; first < n; first += 65535) {
         const int cnt = std::min(65535, n - first);
@@ -1478,7 +1572,6 @@ int do_affine_batch(vt_volume* v, int n, const double* m4x4s, float* out, int fl
     v->last_lds[0] = v->last_lds[1] = v->last_lds[2] = 0;
     v->last_lds_bytes = 0; v->last_grid = (int)((n_out + 255) / 256);
     if (host_out) {
-        PinnedScope pin(out, total * sizeof(float));
         VT_HIP(pin.copy(out, d_out, total * sizeof(float), hipMemcpyDeviceToHost, v->stream));
         VT_HIP(hipStreamSynchronize(v->stream));
     }
@@ -1585,7 +1678,8 @@ int do_project(vt_volume* v, const double m4x4[16], float* out, int flags)
     q.src_pitch = v->oW; q.dst_pitch = v->oW; q.dst_plane = 0; q.copies = 1; q.uniform = 1;
     VT_HIP(launch_plane_sum(v->d_proj_tmp, d_out, q, v->stream));
     if (host_out) {
-        VT_HIP(hipMemcpyAsync(out, d_out, n2 * sizeof(float), hipMemcpyDeviceToHost, v->stream));
+        PinnedScope pin(out, n2 * sizeof(float));
+        VT_HIP(pin.copy(out, d_out, n2 * sizeof(float), hipMemcpyDeviceToHost, v->stream));
         VT_HIP(hipStreamSynchronize(v->stream));
     }
     return 0;
@@ -1670,7 +1764,11 @@ int vt_memcpy_h2d(int dev, void* dptr, const void* hptr, size_t bytes)
     if (!dptr || !hptr) return fail(VT_EINVAL, "NULL pointer");
     int rc = use_device(dev);
     if (rc) return rc;
-    VT_HIP(hipMemcpy(dptr, hptr, bytes, hipMemcpyHostToDevice));
+    {
+        PinnedScope pin(hptr, bytes);
+        VT_HIP(pin.copy(dptr, hptr, bytes, hipMemcpyHostToDevice, nullptr));
+        VT_HIP(hipStreamSynchronize(nullptr));
+    }
     return 0;
 }
 
@@ -1679,7 +1777,11 @@ int vt_memcpy_d2h(int dev, void* hptr, const void* dptr, size_t bytes)
     if (!dptr || !hptr) return fail(VT_EINVAL, "NULL pointer");
     int rc = use_device(dev);
     if (rc) return rc;
-    VT_HIP(hipMemcpy(hptr, dptr, bytes, hipMemcpyDeviceToHost));
+    {
+        PinnedScope pin(hptr, bytes);
+        VT_HIP(pin.copy(hptr, dptr, bytes, hipMemcpyDeviceToHost, nullptr));
+        VT_HIP(hipStreamSynchronize(nullptr));
+    }
     return 0;
 }
 
@@ -1698,6 +1800,7 @@ int vt_host_register(int dev, void* ptr, size_t bytes)
     int rc = use_device(dev);
     if (rc) return rc;
     VT_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    if (std::getenv("VT_DEBUG_PIN")) std::fprintf(stderr, "[vt pin] pool buffer [%p, %p) registered\n", ptr, (void*)((char*)ptr + bytes));
     return 0;
 }
 
@@ -1725,6 +1828,7 @@ int vt_host_unregister(int dev, void* ptr)
     int rc = use_device(dev);
     if (rc) return rc;
     VT_HIP(hipHostUnregister(ptr));
+    if (std::getenv("VT_DEBUG_PIN")) std::fprintf(stderr, "[vt pin] pool buffer %p released\n", ptr);
     return 0;
 }
 
@@ -1779,6 +1883,7 @@ int vt_volume_destroy(vt_volume_t* v)
     if (v->stream) hipStreamSynchronize(v->stream);
     if (v->d_src) cached_free(v->dev, v->d_src, v->src_bytes);
     if (v->d_queue) hipFree(v->d_queue);
+    if (v->d_tile_tbl) hipFree(v->d_tile_tbl);
 #ifdef VT_LEGACY
     if (v->d_src_zp) hipFree(v->d_src_zp);
     if (v->d_src_t_zp) hipFree(v->d_src_t_zp);
