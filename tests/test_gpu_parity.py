@@ -1190,3 +1190,4 @@ def test_row_kernel_with_two_row_buffers_returns_the_same_bits(interp, monkeypat
         assert np.array_equal(got[('0', i)][0], got[('1', i)][0]), i
         assert np.array_equal(got[('0', i)][1], got[('1', i)][1]), i
         assert np.abs(got[('1', i)][0] - oracle.affine(vol, m, interp)).max() <= TOL[interp]
+

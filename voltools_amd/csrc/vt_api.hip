@@ -1016,21 +1016,11 @@ int launch_planned(vt_volume* v, const TilePlan& plan, const AffineParams& p, co
         // last to first -- the control, which measures like 0.)
         AffineParams q = p;
         if (v->tune.quad_pingpong == 2 || (v->tune.quad_pingpong == 1 && ((v->launch_no++) & 1))) q.flags |= (1 << 20);
-        // Tile table (round 5): the in-plane set-up of every tile once per launch, in a one-layer pass in front of the real launch, instead of
-        // once per chunk layer.  For the kinds whose set-up weighs most against a short chunk (integer axis-0 offsets: KIND 3 / 4) from three
-        // layers on; VT_QUAD_TABLE=0 never, 1 for every plane-quad launch on the 2-D grid.  The buffer (16 * NREC4 bytes per thread and
-        // tile: 32 bytes per in-plane output pixel for the headline kernel) belongs to the handle and only grows.
-        const bool zid_kind = (q.flags & ((1 << 25) | (1 << 19))) != 0;
-        const int tq = v->tune.quad_table;
-        if ((q.flags & (1 << 29)) && tq != 0 && (tq > 0 || (zid_kind && q.nTd >= 3))) {
-            const size_t need = quad_table_bytes(plan.cfg, v->interp, zid_kind, (int64_t)q.nTh * q.nTw);
-            if (v->tile_tbl_bytes < need) {
-                if (v->d_tile_tbl) { (void)hipStreamSynchronize(v->stream); (void)hipFree(v->d_tile_tbl); v->d_tile_tbl = nullptr; v->tile_tbl_bytes = 0; }
-                if (hipMalloc(reinterpret_cast<void**>(&v->d_tile_tbl), need) == hipSuccess) v->tile_tbl_bytes = need;
-                else { (void)hipGetLastError(); v->d_tile_tbl = nullptr; }
-            }
-            if (v->d_tile_tbl) { q.tile_tbl = v->d_tile_tbl; q.tbl_mode = 2; }
-        }
+        // (Round 5 measured per-launch TILE TABLES here -- the in-plane set-up of every tile worked out once, by a one-layer pass of the same
+        //  kernel in front of the real launch, and read back by every chunk layer: bit-identical, the real launch faster and flatter over the
+        //  angles, but the pass itself sits in front of every launch with 12-14 us, twice what it saves: 512^3 filt_bspline sweep 0.1983 ms
+        //  against 0.1915, 1024^3 1.586 against 1.565, and the second code path cost the default one 1 %.  profiles/r05_tile_tables.txt;
+        //  not in the tree.)
         VT_HIP(launch_affine_quad(plan.cfg, v->interp, srcq, d_out, q, plan.grid, plan.lds_bytes, v->stream));
 #ifdef VT_LEGACY
     } else if (plan.kind == 5) {
@@ -1883,7 +1873,6 @@ int vt_volume_destroy(vt_volume_t* v)
     if (v->stream) hipStreamSynchronize(v->stream);
     if (v->d_src) cached_free(v->dev, v->d_src, v->src_bytes);
     if (v->d_queue) hipFree(v->d_queue);
-    if (v->d_tile_tbl) hipFree(v->d_tile_tbl);
 #ifdef VT_LEGACY
     if (v->d_src_zp) hipFree(v->d_src_zp);
     if (v->d_src_t_zp) hipFree(v->d_src_t_zp);

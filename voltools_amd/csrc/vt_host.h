@@ -36,7 +36,6 @@ struct Tuning {
     int quad_zid = 1;              // VT_QUAD_ZID=0: trilinear launches with fz == 0 keep the two-plane kernel (round-3 A/B)
     int reorient = 4;              // VT_REORIENT: general matrices sample the resident copy whose rows follow the output's w axis, built at the n-th request (0 = never)
     int rows_pd = 8;               // VT_ROWS_PD=4: the row kernel's pixel tile is 4 x 8 (four waves) instead of 8 x 8
-    int quad_table = -1;           // VT_QUAD_TABLE: -1 = tile tables for the integer-offset plane-quad kinds from three chunk layers on, 0 = never, 1 = every 2-D-grid plane-quad launch
     int no_fused_relayout = 0;     // VT_NO_FUSED_RELAYOUT=1: the plane-quad forms of the in-plane transposed orientation through an exchanged plain copy (rounds 2-4) instead of relayout_zquad_swap12
     int rows_db = 0;               // VT_ROWS_DB: 0 = one run per workgroup (the default: faster), 1 = the row kernel walks a tile's runs with two row buffers where they fit, 2 = the same on the 4 x 8 tile
     int rows = 1;                  // VT_ROWS=0: maps that leave axis 2 alone take the axis-exchange path instead of the row kernel (kind 10)
@@ -90,7 +89,6 @@ struct Tuning {
         rows_pd = num("VT_ROWS_PD", 8);
         rows_db = num("VT_ROWS_DB", 0);
         no_fused_relayout = num("VT_NO_FUSED_RELAYOUT", 0);
-        quad_table = num("VT_QUAD_TABLE", -1);
         reorient = num("VT_REORIENT", 4);
         no_proj_cache = std::getenv("VT_NO_PROJ_CACHE") != nullptr;
         zid_dch = num("VT_ZID_DCH", 0);
@@ -158,8 +156,6 @@ struct vt_volume {
     hipEvent_t evc0 = nullptr, evc1 = nullptr;
     float* spare = nullptr;            // the buffer of the lazy copy evicted last, kept for the next build of that size (a sweep under a budget
     size_t spare_bytes = 0;            // trades one orientation's copy for another's: no hipFree + hipMalloc of gigabytes per switch)
-    int* d_tile_tbl = nullptr;         // plane-quad kernel: the tile table of the launch in flight (vt_kernels_quad.hip); grows, never shrinks
-    size_t tile_tbl_bytes = 0;
     int* d_queue = nullptr;            // lane-block kernel: tile counters (one per XCD + a departure count), zero between launches
     float* d_scratch_out = nullptr;    // staging for host outputs
     double* d_batch_m = nullptr;       // batch launches: n x 12 folded matrices

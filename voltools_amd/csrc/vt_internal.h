@@ -53,9 +53,6 @@ struct AffineParams {
     int32_t lds_cap;           // block kernel: bytes of LDS the box may take (the tile-queue word follows)
     int32_t binc_hi[5][3];     // block kernel: Q32.32 increments of the steps between a thread's eight voxels (+8 w, +8 h, -8 w, +4 d, -8 h),
     uint32_t binc_lo[5][3];    // [step kind][source axis]
-    const int* tile_tbl;       // plane-quad kernel: the launch's tile table (vt_kernels_quad.hip, round 5), or null
-    int32_t tbl_mode;          // 0 = no table, 1 = the table pass, 2 = the launch reads its set-up back
-    int32_t tbl_pad_;
 };
 
 
@@ -229,8 +226,6 @@ hipError_t launch_affine_rows(int interp, int pd, const float* src, float* out, 
 hipError_t launch_relayout_zquad_fir(const float* src, float* dst, int D, int H, int W, int P, int Pq, bool simple, hipStream_t stream);
 // the same two forms of the in-plane transposed orientation, straight from the plain copy (no exchanged plain copy in between)
 hipError_t launch_relayout_zquad_swap12(const float* src, float* dst, int D, int H, int W, int P, int Pq, bool fir, bool simple, hipStream_t stream);
-// bytes of the tile table of a launch of `tiles` in-plane tiles (p.tile_tbl; launch_affine_quad runs the table pass itself when p.tbl_mode == 2)
-size_t quad_table_bytes(int cfg, int interp, bool zid, int64_t tiles);
 hipError_t launch_affine_quad(int cfg, int interp, const float* srcq, float* out, const AffineParams& p,
                               int grid, int lds_bytes, hipStream_t stream);
 // lane-block kernel for general matrices (vt_kernels_block.hip)

@@ -340,14 +340,9 @@ __global__ __launch_bounds__(NT, (KIND == 4 && TH * TW == 2 * NT) ? 4 : 1) void 
         any_valid = any_valid && (hi[r] >= p.vlo[r] - kTileMargin) && (lo[r] < p.vhi[r] + kTileMargin);
         all_valid = all_valid && (lo[r] >= p.vlo[r] + kTileMargin) && (hi[r] < p.vhi[r] - kTileMargin);
     }
-    // Tile tables (round 5): 0 = every workgroup works its set-up out itself; 1 = the TABLE PASS, a launch of one layer of workgroups in front
-    // of the real one whose workgroups do the set-up only and leave its per-thread results in p.tile_tbl; 2 = the real launch, set-up read back.
-    const int tmode = p.tbl_mode;
     const double z_lo = (double)d_begin + p.m[3], z_hi = (double)(d_end - 1) + p.m[3];
-    if (tmode != 1) {                             // (the table pass stands for every chunk of its tile: in-plane validity only)
-        any_valid = any_valid && (z_hi >= p.vlo[0] - kTileMargin) && (z_lo < p.vhi[0] + kTileMargin);
-        all_valid = all_valid && (z_lo >= p.vlo[0] + kTileMargin) && (z_hi < p.vhi[0] - kTileMargin);
-    }
+    any_valid = any_valid && (z_hi >= p.vlo[0] - kTileMargin) && (z_lo < p.vhi[0] + kTileMargin);
+    all_valid = all_valid && (z_lo >= p.vlo[0] + kTileMargin) && (z_hi < p.vhi[0] - kTileMargin);
     const bool keep = (p.flags & VT_KEEP_OUTSIDE) != 0;
     const int64_t ostride = p.ostride, orow = p.orow;     // element strides of an output plane / row (axis swaps)
     // lane -> pixel: position `pos` of the wave's 64 pixels (TW | 64: a pixel row never straddles a wave)
@@ -361,7 +356,7 @@ __global__ __launch_bounds__(NT, (KIND == 4 && TH * TW == 2 * NT) ? 4 : 1) void 
     const int lane_right = lane_perm ? quad_pos_to_lane((pos + 1) & 63) : ((lane_id + 1) & 63);
 
     if (!any_valid) {
-        if (!keep && tmode != 1) {
+        if (!keep) {
 #pragma unroll
             for (int px = 0; px < NPIX; ++px) {
                 const int h = h0 + jh0 + px * RP, w = w0 + kw;
@@ -374,260 +369,41 @@ __global__ __launch_bounds__(NT, (KIND == 4 && TH * TW == 2 * NT) ? 4 : 1) void 
         return;
     }
 
-    // ---- what the pipeline needs from the set-up, per thread ----
-    int voff[kQuadMaxIt];                         // byte offset inside a quad-plane of each vector this thread stages (below: relative to the zero vector's)
-    int q[NPIX][NR];                              // byte offset of the first tap of each tap row inside a ring slot
-    int nvec = 0;
-    int iy[NPIX], ix[NPIX];                       // (box-relative tap origin: the set-up itself and the cold gather path only)
+    // tile-uniform, but float64 -> int conversion is a vector instruction: without the explicit move both floors sit in vector registers
+    // for the whole kernel (the compiler drops __builtin_amdgcn_readfirstlane of a value it knows to be uniform)
+    int o1, o2;
+    {
+        const int f1 = (int)floor(lo[1]), f2 = (int)floor(lo[2]);
+        // The builtin on a value the compiler can no longer prove uniform (it passed through an empty asm statement): the compiler emits
+        // v_readfirstlane_b32 itself, with the wait states its hazard recogniser knows.  (Round 4 wrote the instruction as inline asm with
+        // hand-counted s_nop on both sides -- the recogniser does not look into asm statements, and the row kernel, vt_kernels_rows.hip, got
+        // stale origins from that pattern without the s_nop.  The builtin alone, on a value known to be uniform, is dropped, and both floors
+        // then sit in vector registers for the whole kernel.)
+        int g1 = f1, g2 = f2;
+        asm volatile("" : "+v"(g1), "+v"(g2));
+        o1 = __builtin_amdgcn_readfirstlane(g1);
+        o2 = __builtin_amdgcn_readfirstlane(g2);
+        o1 -= HALO;
+        o2 -= HALO;                               // every position is its own 16-byte vector: no alignment of the origin
+    }
+
+    // ---- per-pixel tap geometry ----
+    int iy[NPIX], ix[NPIX];
     float fy[NPIX], fx[NPIX];
+    float wy[NPIX][4], wx[NPIX][4];
     bool in_yx[NPIX], pix_ok[NPIX];
     int ob[NPIX];                                 // byte offset of the pixel relative to the tile's first voxel
+    const double by = base[1] - (double)o1, bx = base[2] - (double)o2;
 #pragma unroll
     for (int px = 0; px < NPIX; ++px) {
         const int j = jh0 + px * RP;
-        pix_ok[px] = (h0 + j < p.oH) && (w0 + kw < p.oW);
-        ob[px] = (int)(((int64_t)j * orow + kw) * 4);           // < 2^31 (host-checked)
-        iy[px] = 0; ix[px] = 0;
-    }
-    int o1 = 0, o2 = 0;
-
-    // A thread's record in the tile table: voff[] | nvec + in_yx bits | fy[] | fx[] | q[][] two per dword (byte offsets inside a slot,
-    // < 16 * NT * kQuadMaxIt <= 40960), as NREC4 16-byte vectors, vector k of thread t of tile i at ((i * NREC4 + k) * NT + t): every load and
-    // store is a contiguous 16 * NT bytes per workgroup.
-    // Why (round 5): the in-plane set-up below -- float64 pixel geometry, row spans by LDS atomics, two prefix sums, three barriers, the
-    // vector offsets: ~9 000 cycles and about a fifth of the wave instructions of a 32-plane cubic chunk -- depends on the in-plane tile alone,
-    // yet every one of the nTd chunk layers repeated it (512^3 filt_bspline: 16 times per tile).  Several chunks per workgroup on one set-up
-    // lost to the dispatcher's balancing (round 4, profiles/r04_chunk_repetition.txt); here the workgroups stay as short as they were and read
-    // the set-up back: five (cubic, two pixels per thread: four) independent 16-byte loads, no LDS table, no barrier in front of the pipeline.
-    typedef int v4i __attribute__((ext_vector_type(4)));
-    constexpr int NQP = NPIX * NR / 2;
-    constexpr int NI = kQuadMaxIt + 1 + 2 * NPIX + NQP;
-    constexpr int NREC4 = (NI + 3) / 4;
-    static_assert(NR % 2 == 0 && NPIX <= 8, "record packing");
-    bool from_table = false;
-    if (tmode == 2) {
-        const v4i* T = reinterpret_cast<const v4i*>(p.tile_tbl) + ((int64_t)(th_i * p.nTw + tw_i) * NREC4) * NT + tid;
-        int rec[4 * NREC4];
-#pragma unroll
-        for (int k = 0; k < NREC4; ++k) {
-            const v4i r = T[(int64_t)k * NT];
-            rec[4 * k] = r.x; rec[4 * k + 1] = r.y; rec[4 * k + 2] = r.z; rec[4 * k + 3] = r.w;
-        }
-        nvec = rec[kQuadMaxIt] & 0xffff;
-        const int nv64 = (nvec + 63) & ~63;
-        // (a footprint beyond the planned slot -- 0xffff: a tile whose record could not be packed -- takes the set-up below and then the cold path)
-        if (nv64 * 16 <= p.slot_floats * 4 && nv64 <= NT * kQuadMaxIt) {
-            from_table = true;
-#pragma unroll
-            for (int it = 0; it < kQuadMaxIt; ++it) voff[it] = rec[it];
-#pragma unroll
-            for (int px = 0; px < NPIX; ++px) {
-                in_yx[px] = ((rec[kQuadMaxIt] >> (16 + px)) & 1) != 0;
-                fy[px] = __builtin_bit_cast(float, rec[kQuadMaxIt + 1 + px]);
-                fx[px] = __builtin_bit_cast(float, rec[kQuadMaxIt + 1 + NPIX + px]);
-#pragma unroll
-                for (int r = 0; r < NR; ++r) {
-                    const int w = rec[kQuadMaxIt + 1 + 2 * NPIX + (px * NR + r) / 2];
-                    q[px][r] = (r & 1) ? (int)((unsigned)w >> 16) : (w & 0xffff);
-                }
-            }
-        }
-    }
-    if (!from_table) {
-        // tile-uniform, but float64 -> int conversion is a vector instruction: without the explicit move both floors sit in vector registers
-        // for the whole kernel (the compiler drops __builtin_amdgcn_readfirstlane of a value it knows to be uniform)
-        {
-            const int f1 = (int)floor(lo[1]), f2 = (int)floor(lo[2]);
-            // The builtin on a value the compiler can no longer prove uniform (it passed through an empty asm statement): the compiler emits
-            // v_readfirstlane_b32 itself, with the wait states its hazard recogniser knows.  (Round 4 wrote the instruction as inline asm with
-            // hand-counted s_nop on both sides -- the recogniser does not look into asm statements, and the row kernel, vt_kernels_rows.hip, got
-            // stale origins from that pattern without the s_nop.  The builtin alone, on a value known to be uniform, is dropped, and both floors
-            // then sit in vector registers for the whole kernel.)
-            int g1 = f1, g2 = f2;
-            asm volatile("" : "+v"(g1), "+v"(g2));
-            o1 = __builtin_amdgcn_readfirstlane(g1);
-            o2 = __builtin_amdgcn_readfirstlane(g2);
-            o1 -= HALO;
-            o2 -= HALO;                               // every position is its own 16-byte vector: no alignment of the origin
-        }
-
-        // ---- per-pixel tap geometry ----
-        const double by = base[1] - (double)o1, bx = base[2] - (double)o2;
-#pragma unroll
-        for (int px = 0; px < NPIX; ++px) {
-            const int j = jh0 + px * RP;
-            const double sy = fma(p.m[5], (double)j, fma(p.m[6], (double)kw, by));
-            const double sx = fma(p.m[9], (double)j, fma(p.m[10], (double)kw, bx));
-            const double fyd = floor(sy), fxd = floor(sx);
-            fy[px] = (float)(sy - fyd);
-            fx[px] = (float)(sx - fxd);
-            iy[px] = (int)fyd;
-            ix[px] = (int)fxd;
-            // rows 1, 2 of an axis-0-separable matrix ignore d
-            in_yx[px] = all_valid || (canonical_inside_axis(p, 1, 0, h0 + j, w0 + kw) && canonical_inside_axis(p, 2, 0, h0 + j, w0 + kw));
-        }
-
-#ifdef VT_EXPERIMENTS
-        stamp[1] = clock64();
-#endif
-        // ---- row spans of the footprint, packed (one vector per position) ----
-        // Exact and integer-only: every pixel taps columns [ix - HALO, ix + HALO + 1] of rows iy - HALO .. iy + HALO + 1 of the
-        // box.  Along a pixel row (lanes kw = 0 .. TW-1 of equal j) iy and ix are monotone in kw, so the lanes that tap a given
-        // source row form a run whose extreme columns sit at the run's two ends: only lanes at a run boundary record their
-        // columns (LDS min / max), which keeps same-address contention at a handful of lanes at every angle.  One wave then
-        // turns (min, max) per row into (span start, first vector) by a 64-entry prefix sum and writes each vector's row index.
-        // (The first version computed the spans analytically in float64 on one wave, march_row_span -- 200 float64 operations on the
-        // critical path of every workgroup while three waves waited; the host still sizes the slot with that superset.)
-        {
-            int* tab = reinterpret_cast<int*>(lds);   // [0..63] column min -> span start, [64..127] column max -> first vector, [128] total
-            unsigned char* vrow = reinterpret_cast<unsigned char*>(tab + kTabInts);
-#ifdef VT_QUAD_ANALYTIC_SPANS                     // A/B: the float64 polygon clipping of the plain / pair marching kernels
-            build_span_table<TH, TW, HALO, 1>(tab, p, p.Ly, by, bx, tid);
-#else
-            if (tid < 2 * kRowsMax) tab[tid] = (tid < kRowsMax) ? 0x7fffffff : (int)0x80000000;
-            __syncthreads();
-#pragma unroll
-            for (int px = 0; px < NPIX; ++px) {
-                // neighbours along the pixel row (TW divides 64: a pixel row never straddles a wave)
-                const int iy_l = __shfl(iy[px], lane_left), iy_r = __shfl(iy[px], lane_right);
-                const bool edge = (kw == 0) || (kw == TW - 1) || (iy_l != iy[px]) || (iy_r != iy[px]);
-                if (edge) {
-#pragma unroll
-                    for (int r = 0; r < NR; ++r) {
-                        const int row = min(max(iy[px] - HALO + r, 0), kRowsMax - 1);
-                        atomicMin(&tab[row], ix[px] - HALO);
-                        atomicMax(&tab[kRowsMax + row], ix[px] + HALO + 1);
-                    }
-                }
-            }
-            __syncthreads();
-#ifdef VT_EXPERIMENTS
-            stamp[2] = clock64();
-#endif
-            if (tid < kRowsMax) {
-                const int lane = tid;
-                const int mn = tab[lane], mx = tab[kRowsMax + lane];
-                const bool used = mn <= mx;
-                const int x0 = used ? mn : 0;
-                const int nv = used ? (mx - mn + 1) : 0;
-                int first, pad = 0, total;
-                {
-                    const int incl = wave_scan_add(nv);
-                    first = incl - nv;
-                    total = __builtin_amdgcn_readlane(incl, 63);
-                }
-                if (p.row_s >= 0) {
-                    // Bank-aware row starts (cubic): row r starts at a slot = x0 + r * S (mod 16), i.e. the image behaves like a box
-                    // with row stride S in the 16-slot bank space of ds_read_b128 while only the spans are stored.  The gaps (< 16
-                    // vectors per row) are filled from the zero vector.  S comes from the host's model of the gather's lane groups
-                    // (vt_plan.hip: S = 0 with the service-group lane mapping, quad_row_stride's model otherwise).  If the padded image does
-                    // not fit the slot, the unpadded prefix sum above stays.
-                    // Every row start is pinned to a residue c_r = (x0_r + r * S) mod 16, so the gap in front of row r depends on its
-                    // predecessor alone: gap_r = (c_r - c_{r-1} - n_{r-1}) mod 16 -- the placement is one more prefix sum, not a walk over
-                    // the rows (round 2 walked them with readlane in a scalar loop: ~35 dependent iterations while three waves waited).
-                    // Rows in use are usually contiguous (the footprint is convex), but an in-plane minification beyond the stencil's reach
-                    // leaves unused box rows between them: the predecessor is the last row IN USE before this one (a max-scan of the
-                    // used rows' indices finds it); the rows before the first one carry residue 0 and length 0.
-                    const int S = p.row_s;
-                    const int c_r = (x0 + lane * S) & 15;
-                    const int end_res = (nv > 0) ? ((c_r + nv) & 15) : 0;            // residue of the position right behind this row
-                    const int last_used = wave_scan_max((nv > 0) ? lane : -1);
-                    const int prev_row = wave_shift_up1(last_used, -1);              // last row in use strictly before this one (-1: none)
-                    int prev_end = __shfl(end_res, max(prev_row, 0));
-                    if (lane == 0 || prev_row < 0) prev_end = 0;                     // first row in use: the image starts at position 0
-                    const int gap = (nv > 0) ? ((c_r - prev_end) & 15) : 0;
-                    const int inc2 = wave_scan_add(gap + nv);
-                    const int first_p = inc2 - nv, pad_p = gap;
-                    const int pos = __builtin_amdgcn_readlane(inc2, 63);
-                    if (((pos + 63) & ~63) * 16 <= p.slot_floats * 4 && pos <= NT * kQuadMaxIt) { first = first_p; pad = pad_p; total = pos; }
-                }
-                tab[lane] = x0;
-                tab[kRowsMax + lane] = first;
-                if (lane == 0) tab[2 * kRowsMax] = total;
-                const int last = min(first + nv, kVrowCap);
-                for (int v = max(first - pad, 0); v < min(first, kVrowCap); ++v) vrow[v] = 255;
-                // a row's run of entries: bytes up to the next word, whole words, bytes (runs of different lanes share words only at their ends)
-                int v = first;
-                for (; v < last && (v & 3); ++v) vrow[v] = (unsigned char)lane;
-                const unsigned lane4 = (unsigned)lane * 0x01010101u;
-                for (; v + 4 <= last; v += 4) *reinterpret_cast<unsigned*>(vrow + v) = lane4;
-                for (; v < last; ++v) vrow[v] = (unsigned char)lane;
-            }
-            __syncthreads();
-#endif
-#ifdef VT_EXPERIMENTS
-            stamp[3] = clock64();
-#endif
-            nvec = tab[2 * kRowsMax];
-#pragma unroll
-            for (int it = 0; it < kQuadMaxIt; ++it) {
-                const int v = tid + NT * it;
-                const int y = (v < nvec && v < kVrowCap) ? vrow[v] : 255;
-                const int yy = (y == 255) ? 0 : y;
-                const int cx = v - tab[kRowsMax + yy];
-                const int gy = o1 + yy, gx = o2 + tab[yy] + cx;
-                const bool ok = (y != 255) && (unsigned)gy < (unsigned)p.sH && (unsigned)gx < (unsigned)p.sW;
-                voff[it] = ok ? (gy * p.sPq + 4 * gx) * 4 : p.zero_off_q;
-            }
-#pragma unroll
-            for (int px = 0; px < NPIX; ++px) {
-#pragma unroll
-                for (int r = 0; r < NR; ++r) {
-                    const int row = min(max(iy[px] - HALO + r, 0), kRowsMax - 1);
-                    q[px][r] = 16 * (tab[kRowsMax + row] + (ix[px] - HALO - tab[row]));
-                }
-            }
-            __syncthreads();                          // the table is dead from here on; the ring may be written
-        }
-    // voff[] now holds each vector's offset RELATIVE to the zero vector's: a quad outside the resident copy is staged from the zero
-    // vector by masking that difference (off = zero_off + (voff & mask), mask wave-uniform) -- pure arithmetic.  The obvious form,
-    // `quad_ok ? voff[it] : p.zero_off_q`, selects between two lvalues the nested lambdas below reach through references; the
-    // compiler turned it into a select of two ADDRESSES followed by one load, which kept voff[] in scratch memory in the trilinear
-    // instantiations: 3 dword stores per thread and workgroup, 9 % more bytes written to HBM than the output itself at 16-plane chunks
-    // (WRITE_SIZE 1.088x at 16 planes, 1.044x at 32: profiles/r04_write_size_variants.txt).
-#pragma unroll
-        for (int it = 0; it < kQuadMaxIt; ++it) voff[it] -= p.zero_off_q;
-        if (tmode == 1) {
-            // the table pass: leave the record and go.  Offsets that do not fit their 16 bits (none can: every tap row of every pixel lies inside
-            // the packed image) would mark the whole tile "no table".
-            int bad = 0;
-#pragma unroll
-            for (int px = 0; px < NPIX; ++px)
-#pragma unroll
-                for (int r = 0; r < NR; ++r) bad |= ((unsigned)q[px][r] >= 65536u) ? 1 : 0;
-            {
-                int* flag = reinterpret_cast<int*>(lds);               // (the span table is dead: the set-up's last barrier is behind us)
-                if (tid == 0) *flag = 0;
-                __syncthreads();
-                if (bad) atomicOr(flag, 1);
-                __syncthreads();
-                bad = *flag;
-            }
-            int rec[4 * NREC4];
-#pragma unroll
-            for (int k = 0; k < 4 * NREC4; ++k) rec[k] = 0;
-#pragma unroll
-            for (int it = 0; it < kQuadMaxIt; ++it) rec[it] = voff[it];
-            int hdr = (bad || nvec > 0xfffe) ? 0xffff : nvec;
-#pragma unroll
-            for (int px = 0; px < NPIX; ++px) {
-                hdr |= (in_yx[px] ? 1 : 0) << (16 + px);
-                rec[kQuadMaxIt + 1 + px] = __builtin_bit_cast(int, fy[px]);
-                rec[kQuadMaxIt + 1 + NPIX + px] = __builtin_bit_cast(int, fx[px]);
-#pragma unroll
-                for (int r = 0; r < NR; r += 2)
-                    rec[kQuadMaxIt + 1 + 2 * NPIX + (px * NR + r) / 2] = (q[px][r] & 0xffff) | (int)((unsigned)q[px][r + 1] << 16);
-            }
-            rec[kQuadMaxIt] = hdr;
-            v4i* T = reinterpret_cast<v4i*>(const_cast<int*>(p.tile_tbl)) + ((int64_t)(th_i * p.nTw + tw_i) * NREC4) * NT + tid;
-#pragma unroll
-            for (int k = 0; k < NREC4; ++k) T[(int64_t)k * NT] = v4i{rec[4 * k], rec[4 * k + 1], rec[4 * k + 2], rec[4 * k + 3]};
-            return;
-        }
-    }
-    float wy[NPIX][4], wx[NPIX][4];
-#pragma unroll
-    for (int px = 0; px < NPIX; ++px) {
+        const double sy = fma(p.m[5], (double)j, fma(p.m[6], (double)kw, by));
+        const double sx = fma(p.m[9], (double)j, fma(p.m[10], (double)kw, bx));
+        const double fyd = floor(sy), fxd = floor(sx);
+        fy[px] = (float)(sy - fyd);
+        fx[px] = (float)(sx - fxd);
+        iy[px] = (int)fyd;
+        ix[px] = (int)fxd;
         if constexpr (KIND == 4) {
             if (p.flags & (1 << 18)) { cubic_weights<true>(fy[px], wy[px]); cubic_weights<true>(fx[px], wx[px]); }
             else { cubic_weights<false>(fy[px], wy[px]); cubic_weights<false>(fx[px], wx[px]); }
@@ -636,7 +412,135 @@ __global__ __launch_bounds__(NT, (KIND == 4 && TH * TW == 2 * NT) ? 4 : 1) void 
 #pragma unroll
             for (int k = 0; k < 4; ++k) { wy[px][k] = 0.f; wx[px][k] = 0.f; }
         }
+        // rows 1, 2 of an axis-0-separable matrix ignore d
+        in_yx[px] = all_valid || (canonical_inside_axis(p, 1, 0, h0 + j, w0 + kw) && canonical_inside_axis(p, 2, 0, h0 + j, w0 + kw));
+        pix_ok[px] = (h0 + j < p.oH) && (w0 + kw < p.oW);
+        ob[px] = (int)(((int64_t)j * orow + kw) * 4);           // < 2^31 (host-checked)
     }
+
+#ifdef VT_EXPERIMENTS
+    stamp[1] = clock64();
+#endif
+    // ---- row spans of the footprint, packed (one vector per position) ----
+    // Exact and integer-only: every pixel taps columns [ix - HALO, ix + HALO + 1] of rows iy - HALO .. iy + HALO + 1 of the
+    // box.  Along a pixel row (lanes kw = 0 .. TW-1 of equal j) iy and ix are monotone in kw, so the lanes that tap a given
+    // source row form a run whose extreme columns sit at the run's two ends: only lanes at a run boundary record their
+    // columns (LDS min / max), which keeps same-address contention at a handful of lanes at every angle.  One wave then
+    // turns (min, max) per row into (span start, first vector) by a 64-entry prefix sum and writes each vector's row index.
+    // (The first version computed the spans analytically in float64 on one wave, march_row_span -- 200 float64 operations on the
+    // critical path of every workgroup while three waves waited; the host still sizes the slot with that superset.)
+    int voff[kQuadMaxIt];                         // byte offset inside a quad-plane of each vector this thread stages
+    int q[NPIX][NR];                              // byte offset of the first tap of each tap row inside a ring slot
+    int nvec;
+    {
+        int* tab = reinterpret_cast<int*>(lds);   // [0..63] column min -> span start, [64..127] column max -> first vector, [128] total
+        unsigned char* vrow = reinterpret_cast<unsigned char*>(tab + kTabInts);
+#ifdef VT_QUAD_ANALYTIC_SPANS                     // A/B: the float64 polygon clipping of the plain / pair marching kernels
+        build_span_table<TH, TW, HALO, 1>(tab, p, p.Ly, by, bx, tid);
+#else
+        if (tid < 2 * kRowsMax) tab[tid] = (tid < kRowsMax) ? 0x7fffffff : (int)0x80000000;
+        __syncthreads();
+#pragma unroll
+        for (int px = 0; px < NPIX; ++px) {
+            // neighbours along the pixel row (TW divides 64: a pixel row never straddles a wave)
+            const int iy_l = __shfl(iy[px], lane_left), iy_r = __shfl(iy[px], lane_right);
+            const bool edge = (kw == 0) || (kw == TW - 1) || (iy_l != iy[px]) || (iy_r != iy[px]);
+            if (edge) {
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const int row = min(max(iy[px] - HALO + r, 0), kRowsMax - 1);
+                    atomicMin(&tab[row], ix[px] - HALO);
+                    atomicMax(&tab[kRowsMax + row], ix[px] + HALO + 1);
+                }
+            }
+        }
+        __syncthreads();
+#ifdef VT_EXPERIMENTS
+        stamp[2] = clock64();
+#endif
+        if (tid < kRowsMax) {
+            const int lane = tid;
+            const int mn = tab[lane], mx = tab[kRowsMax + lane];
+            const bool used = mn <= mx;
+            const int x0 = used ? mn : 0;
+            const int nv = used ? (mx - mn + 1) : 0;
+            int first, pad = 0, total;
+            {
+                const int incl = wave_scan_add(nv);
+                first = incl - nv;
+                total = __builtin_amdgcn_readlane(incl, 63);
+            }
+            if (p.row_s >= 0) {
+                // Bank-aware row starts (cubic): row r starts at a slot = x0 + r * S (mod 16), i.e. the image behaves like a box
+                // with row stride S in the 16-slot bank space of ds_read_b128 while only the spans are stored.  The gaps (< 16
+                // vectors per row) are filled from the zero vector.  S comes from the host's model of the gather's lane groups
+                // (vt_plan.hip: S = 0 with the service-group lane mapping, quad_row_stride's model otherwise).  If the padded image does
+                // not fit the slot, the unpadded prefix sum above stays.
+                // Every row start is pinned to a residue c_r = (x0_r + r * S) mod 16, so the gap in front of row r depends on its
+                // predecessor alone: gap_r = (c_r - c_{r-1} - n_{r-1}) mod 16 -- the placement is one more prefix sum, not a walk over
+                // the rows (round 2 walked them with readlane in a scalar loop: ~35 dependent iterations while three waves waited).
+                // Rows in use are usually contiguous (the footprint is convex), but an in-plane minification beyond the stencil's reach
+                // leaves unused box rows between them: the predecessor is the last row IN USE before this one (a max-scan of the
+                // used rows' indices finds it); the rows before the first one carry residue 0 and length 0.
+                const int S = p.row_s;
+                const int c_r = (x0 + lane * S) & 15;
+                const int end_res = (nv > 0) ? ((c_r + nv) & 15) : 0;            // residue of the position right behind this row
+                const int last_used = wave_scan_max((nv > 0) ? lane : -1);
+                const int prev_row = wave_shift_up1(last_used, -1);              // last row in use strictly before this one (-1: none)
+                int prev_end = __shfl(end_res, max(prev_row, 0));
+                if (lane == 0 || prev_row < 0) prev_end = 0;                     // first row in use: the image starts at position 0
+                const int gap = (nv > 0) ? ((c_r - prev_end) & 15) : 0;
+                const int inc2 = wave_scan_add(gap + nv);
+                const int first_p = inc2 - nv, pad_p = gap;
+                const int pos = __builtin_amdgcn_readlane(inc2, 63);
+                if (((pos + 63) & ~63) * 16 <= p.slot_floats * 4 && pos <= NT * kQuadMaxIt) { first = first_p; pad = pad_p; total = pos; }
+            }
+            tab[lane] = x0;
+            tab[kRowsMax + lane] = first;
+            if (lane == 0) tab[2 * kRowsMax] = total;
+            const int last = min(first + nv, kVrowCap);
+            for (int v = max(first - pad, 0); v < min(first, kVrowCap); ++v) vrow[v] = 255;
+            // a row's run of entries: bytes up to the next word, whole words, bytes (runs of different lanes share words only at their ends)
+            int v = first;
+            for (; v < last && (v & 3); ++v) vrow[v] = (unsigned char)lane;
+            const unsigned lane4 = (unsigned)lane * 0x01010101u;
+            for (; v + 4 <= last; v += 4) *reinterpret_cast<unsigned*>(vrow + v) = lane4;
+            for (; v < last; ++v) vrow[v] = (unsigned char)lane;
+        }
+        __syncthreads();
+#endif
+#ifdef VT_EXPERIMENTS
+        stamp[3] = clock64();
+#endif
+        nvec = tab[2 * kRowsMax];
+#pragma unroll
+        for (int it = 0; it < kQuadMaxIt; ++it) {
+            const int v = tid + NT * it;
+            const int y = (v < nvec && v < kVrowCap) ? vrow[v] : 255;
+            const int yy = (y == 255) ? 0 : y;
+            const int cx = v - tab[kRowsMax + yy];
+            const int gy = o1 + yy, gx = o2 + tab[yy] + cx;
+            const bool ok = (y != 255) && (unsigned)gy < (unsigned)p.sH && (unsigned)gx < (unsigned)p.sW;
+            voff[it] = ok ? (gy * p.sPq + 4 * gx) * 4 : p.zero_off_q;
+        }
+#pragma unroll
+        for (int px = 0; px < NPIX; ++px) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int row = min(max(iy[px] - HALO + r, 0), kRowsMax - 1);
+                q[px][r] = 16 * (tab[kRowsMax + row] + (ix[px] - HALO - tab[row]));
+            }
+        }
+        __syncthreads();                          // the table is dead from here on; the ring may be written
+    }
+    // voff[] now holds each vector's offset RELATIVE to the zero vector's: a quad outside the resident copy is staged from the zero
+    // vector by masking that difference (off = zero_off + (voff & mask), mask wave-uniform) -- pure arithmetic.  The obvious form,
+    // `quad_ok ? voff[it] : p.zero_off_q`, selects between two lvalues the nested lambdas below reach through references; the
+    // compiler turned it into a select of two ADDRESSES followed by one load, which kept voff[] in scratch memory in the trilinear
+    // instantiations: 3 dword stores per thread and workgroup, 9 % more bytes written to HBM than the output itself at 16-plane chunks
+    // (WRITE_SIZE 1.088x at 16 planes, 1.044x at 32: profiles/r04_write_size_variants.txt).
+#pragma unroll
+    for (int it = 0; it < kQuadMaxIt; ++it) voff[it] -= p.zero_off_q;
     const int nvec64 = (nvec + 63) & ~63;         // whole waves stage: a wave's instruction is issued in full or not at all
     const int slot_bytes = p.slot_floats * 4;
 
@@ -928,26 +832,8 @@ hipError_t launch_affine_quad(int cfg, int interp, const float* srcq, float* out
     const int kind = ((p.flags & (1 << 25)) && ik == 0) ? 3 : (((p.flags & (1 << 19)) && ik != 0) ? 4 : ik);
     quad_fn fn = quad_entry(cfg, kind);
     const dim3 g = (p.flags & (1 << 29)) ? dim3((unsigned)(p.nTh * p.nTw), (unsigned)p.nTd) : dim3((unsigned)grid);
-    if (p.tbl_mode == 2) {
-        // the table pass: one layer of workgroups, the same kernel, the same thread-to-pixel mapping -- set-up only, left in p.tile_tbl
-        if (!(p.flags & (1 << 29)) || !p.tile_tbl) return hipErrorInvalidValue;
-        AffineParams pt = p;
-        pt.tbl_mode = 1;
-        hipLaunchKernelGGL(fn, dim3(g.x, 1), dim3(kQuad[cfg].nt), lds_bytes, stream, srcq, out, pt);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
-    }
     hipLaunchKernelGGL(fn, g, dim3(kQuad[cfg].nt), lds_bytes, stream, srcq, out, p);
     return hipGetLastError();
-}
-
-size_t quad_table_bytes(int cfg, int interp, bool zid, int64_t tiles)
-{
-    const int npix = kQuad[cfg].th * kQuad[cfg].tw / kQuad[cfg].nt;
-    const int nr = interp_kind(interp) == 0 ? 2 : 4;
-    const int ni = kQuadMaxIt + 1 + 2 * npix + npix * nr / 2;            // affine_march4: NI
-    (void)zid;
-    return (size_t)tiles * ((ni + 3) / 4) * kQuad[cfg].nt * 16;
 }
 
 }  // namespace vt
