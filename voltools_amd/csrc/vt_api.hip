@@ -298,7 +298,10 @@ namespace {
 // registered here, two pinned objects cover the same pages: the registration succeeds, the copy resolves its host address to the OLD,
 // smaller object and runs off its end -- or the old pin is dropped from the cache under the copy -- and the GPU faults inside a range that
 // was registered "ok" a moment ago.  (The trace: four 1.3 MB results at 0x..3d8eef90 .. 0x..3dcbd840, then a 32 MB input at 0x..3d8eef90,
-// interior [0x..3da00000, 0x..3f600000) registered ok, fault at 0x..3f3c7000.)  Two rules follow:
+// interior [0x..3da00000, 0x..3f600000) registered ok, fault at 0x..3f3c7000.  What the trace does not show is the step in between: the
+// small arrays were FREED, the heap gave their pages back, and the next array got new pages at the old addresses -- a replay of the same
+// transfers inside one arena whose pages never go away does not fault, tools/diag/pin_probe_check.py: the stale object is a pin whose pages
+// are gone.)  Two rules follow:
 //   1. no transfer issued here is ever pinned by the runtime: every pageable piece goes in slices of kSlice = 512 KiB, half the runtime's
 //      threshold, i.e. through its staging buffers (1-8 MiB arrays lose the pinned rate they used to get: 0.3 ms on 4 MiB);
 //   2. nothing is registered over a range in which the runtime already knows a pinned object (somebody else's pageable transfer, a caller's
@@ -306,7 +309,7 @@ namespace {
 struct PinnedScope {
     void* ptr = nullptr;
     bool pinned = false;
-    static bool trace() { static const bool t = std::getenv("VT_DEBUG_PIN") != nullptr; return t; }
+    static bool trace() { return std::getenv("VT_DEBUG_PIN") != nullptr; }      // (read per scope: a test switches it on for one call)
     // Memory the runtime already knows as pinned host memory (the Python layer's pooled result buffers, a caller's own
     // hipHostMalloc / hipHostRegister, the runtime's own pins): registering the same range a second time SUCCEEDS, and the matching
     // unregister at the end of the scope then strips the owner's registration ([measured, round 2] the pool's later
@@ -364,6 +367,8 @@ struct PinnedScope {
     // one pageable piece, in slices the runtime stages (rule 1)
     static hipError_t sliced(char* dst, const char* src, size_t bytes, hipMemcpyKind kind, hipStream_t st)
     {
+        // VT_PIN_UNSLICED=1 (diagnosis only: tools/diag/pin_probe_check.py): one transfer, which the runtime pins in place when it is large
+        if (std::getenv("VT_PIN_UNSLICED")) return hipMemcpyAsync(dst, src, bytes, kind, st);
         for (size_t off = 0; off < bytes; off += kSlice) {
             const hipError_t e = hipMemcpyAsync(dst + off, src + off, std::min(kSlice, bytes - off), kind, st);
             if (e != hipSuccess) return e;
