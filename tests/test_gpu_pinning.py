@@ -38,7 +38,7 @@ def carve(base, byte_offset, shape):
 
 
 def test_ragged_host_ranges_round_trip_bit_for_bit():
-    shape = (96, 200, 208)                                   # 15.2 MiB: an interior of six or seven whole units, ragged ends
+    shape = (210, 200, 208)                                  # 33.3 MiB (arrays up to 32 MiB are never registered: they could live in the process heap): an interior of fifteen or sixteen whole units, ragged ends
     n = int(np.prod(shape))
     arena = np.frombuffer(mmap.mmap(-1, 4 * n * 2 + 8 * UNIT), dtype=np.uint8)
     first = (-arena.ctypes.data) % UNIT                      # arena[first] sits on the 2 MiB grid
@@ -66,7 +66,7 @@ def test_ragged_host_ranges_round_trip_bit_for_bit():
 
 def test_registered_result_survives_temporary_pins_in_the_same_huge_page_mapping():
     shape_res = (80, 128, 136)                               # 5.3 MiB result: pooled only with VT_HOST_POOL_MIN_MB lowered -- use a big one
-    shape_big = (130, 128, 136)                              # 8.6 MiB: above the pool and the pinning thresholds
+    shape_big = (260, 192, 176)                              # 33.5 MiB: above the pool's and the registration's thresholds
     nb = int(np.prod(shape_big))
     mm = mmap.mmap(-1, 4 * nb * 3 + 8 * UNIT)
     if hasattr(mmap, 'MADV_HUGEPAGE'):
@@ -109,8 +109,8 @@ def test_small_results_then_a_large_source_at_the_same_addresses():
     in-place pinning threshold), then a 32 MB source array over the same addresses whose interior gets registered -- in one arena, so that
     the addresses coincide by construction and not by the heap's mood."""
     from oracle import oracle
-    small_shape, big_shape = (70, 66, 72), (200, 200, 200)
-    arena = np.frombuffer(mmap.mmap(-1, 4 * 200 ** 3 + 4 * UNIT), dtype=np.uint8)
+    small_shape, big_shape = (70, 66, 72), (208, 208, 208)                  # 1.33 MB; 34.3 MiB (registered: larger than anything the heap holds)
+    arena = np.frombuffer(mmap.mmap(-1, 4 * 208 ** 3 + 4 * UNIT), dtype=np.uint8)
     base = (-arena.ctypes.data) % UNIT + 0xeef90 % 4096 + 4096 * 17        # an unaligned start, as the heap's was
     rs = np.random.RandomState(11)
     vol_s = rs.random_sample(small_shape).astype(np.float32)
@@ -144,8 +144,8 @@ def test_a_foreign_pin_under_a_callers_array_is_left_alone(capfd, monkeypatch):
     the foreign pin is printed under VT_DEBUG_PIN and reported, the result must be right either way."""
     torch = pytest.importorskip('torch')
     monkeypatch.setenv('VT_DEBUG_PIN', '1')
-    shape = (160, 160, 160)                                   # 15.6 MiB
-    arena = np.frombuffer(mmap.mmap(-1, 4 * 160 ** 3 + 4 * UNIT), dtype=np.uint8)
+    shape = (208, 208, 208)                                   # 34.3 MiB
+    arena = np.frombuffer(mmap.mmap(-1, 4 * 208 ** 3 + 4 * UNIT), dtype=np.uint8)
     base = (-arena.ctypes.data) % UNIT + 4096 * 5 + 48
     vol = carve(arena, base, shape)
     vol[...] = np.random.RandomState(12).random_sample(shape).astype(np.float32)

@@ -3,6 +3,7 @@
 #include "vt_device.h"
 #include "vt_host.h"
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -13,6 +14,8 @@
 #include <new>
 #include <unordered_map>
 #include <vector>
+
+#include <unistd.h>
 
 using namespace vt;
 
@@ -310,6 +313,38 @@ struct PinnedScope {
     void* ptr = nullptr;
     bool pinned = false;
     static bool trace() { return std::getenv("VT_DEBUG_PIN") != nullptr; }      // (read per scope: a test switches it on for one call)
+    // VT_DEBUG_PIN=1: to stderr; VT_DEBUG_PIN=<path with a slash>: appended to that file line by line (a trace that survives the abort of a
+    // GPU fault under a test runner that captures stderr)
+    static void say(const char* fmt, ...) __attribute__((format(printf, 1, 2)))
+    {
+        const char* e = std::getenv("VT_DEBUG_PIN");
+        if (!e) return;
+        FILE* f = std::strchr(e, '/') ? std::fopen(e, "a") : stderr;
+        if (!f) return;
+        va_list ap;
+        va_start(ap, fmt);
+        std::vfprintf(f, fmt, ap);
+        va_end(ap);
+        if (f != stderr) std::fclose(f); else std::fflush(f);
+    }
+    // The process heap [start of the [heap] mapping, current break): arrays that live there are never registered (rule 3 below).
+    static bool in_brk_heap(const void* p, size_t bytes)
+    {
+        static std::atomic<uintptr_t> heap_lo{0};
+        uintptr_t lo_ = heap_lo.load(std::memory_order_relaxed);
+        if (!lo_) {
+            if (FILE* f = std::fopen("/proc/self/maps", "r")) {
+                char line[512];
+                while (std::fgets(line, sizeof line, f))
+                    if (std::strstr(line, "[heap]")) { lo_ = (uintptr_t)std::strtoull(line, nullptr, 16); break; }
+                std::fclose(f);
+            }
+            if (lo_) heap_lo.store(lo_, std::memory_order_relaxed);
+        }
+        if (!lo_) return false;
+        const uintptr_t a = reinterpret_cast<uintptr_t>(p), brk_now = reinterpret_cast<uintptr_t>(sbrk(0));
+        return a + bytes > lo_ && a < brk_now;
+    }
     // Memory the runtime already knows as pinned host memory (the Python layer's pooled result buffers, a caller's own
     // hipHostMalloc / hipHostRegister, the runtime's own pins): registering the same range a second time SUCCEEDS, and the matching
     // unregister at the end of the scope then strips the owner's registration ([measured, round 2] the pool's later
@@ -338,22 +373,27 @@ struct PinnedScope {
     mutable bool used_stream = false;
     static constexpr uintptr_t kUnit = 2u << 20;
     static constexpr size_t kSlice = 512u << 10;
+    static constexpr size_t kHeapMax = 32u << 20;          // glibc's DEFAULT_MMAP_THRESHOLD_MAX on 64-bit
     PinnedScope(const void* p, size_t bytes)
     {
         static const bool off = std::getenv("VT_NO_PIN") != nullptr;
-        if (trace() && p) std::fprintf(stderr, "[vt pin] scope %p + %zu\n", p, bytes);
-        if (off || !p || bytes < (8u << 20)) return;
+        if (trace() && p) say("[vt pin] scope %p + %zu%s\n", p, bytes, in_brk_heap(p, bytes) ? " (process heap)" : "");
+        // Rule 3: nothing in the process heap is registered, and nothing the heap COULD hold: glibc serves requests up to 32 MiB from the
+        // heap once its dynamic mmap threshold has risen (it rises to the size of every freed mapping up to that maximum), larger ones always
+        // from mappings of their own.  Every fault seen -- rounds 1, 2, 4 and three this round -- was at a heap address, inside an interior
+        // registered "ok" a moment before, after the heap had taken pages back and handed the addresses out again (profiles/r05_pin_trace.txt).
+        if (off || !p || bytes <= kHeapMax || in_brk_heap(p, bytes)) return;
         const uintptr_t a0 = (reinterpret_cast<uintptr_t>(p) + kUnit - 1) & ~(kUnit - 1);
         const uintptr_t a1 = (reinterpret_cast<uintptr_t>(p) + bytes) & ~(kUnit - 1);
         if (a1 <= a0 || a1 - a0 < (4u << 20)) return;
         // (the head and tail are probed too: a runtime pin that starts in the head reaches into the interior)
         if (any_registered(reinterpret_cast<uintptr_t>(p), reinterpret_cast<uintptr_t>(p) + bytes)) {
-            if (trace()) std::fprintf(stderr, "[vt pin] %p + %zu overlaps memory the runtime has pinned already: not registered\n", p, bytes);
+            if (trace()) say("[vt pin] %p + %zu overlaps memory the runtime has pinned already: not registered\n", p, bytes);
             return;
         }
         ptr = reinterpret_cast<void*>(a0);
         pinned = hipHostRegister(ptr, a1 - a0, hipHostRegisterDefault) == hipSuccess;
-        if (trace()) std::fprintf(stderr, "[vt pin] registered [%p, %p): %s\n", ptr, (void*)a1, pinned ? "ok" : "refused");
+        if (trace()) say("[vt pin] registered [%p, %p): %s\n", ptr, (void*)a1, pinned ? "ok" : "refused");
         if (!pinned) { (void)hipGetLastError(); return; }
         lo = reinterpret_cast<char*>(a0);
         hi = reinterpret_cast<char*>(a1);
@@ -457,7 +497,7 @@ struct PinnedScope {
         //  return in between has not)
         if (used_stream) (void)hipStreamSynchronize(last_stream);
         const hipError_t e = hipHostUnregister(ptr);
-        if (trace()) std::fprintf(stderr, "[vt pin] released [%p, %p): %s\n", ptr, (void*)hi, e == hipSuccess ? "ok" : hipGetErrorString(e));
+        if (trace()) say("[vt pin] released [%p, %p): %s\n", ptr, (void*)hi, e == hipSuccess ? "ok" : hipGetErrorString(e));
         if (e != hipSuccess) (void)hipGetLastError();
     }
 };
@@ -1795,7 +1835,7 @@ int vt_host_register(int dev, void* ptr, size_t bytes)
     int rc = use_device(dev);
     if (rc) return rc;
     VT_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
-    if (std::getenv("VT_DEBUG_PIN")) std::fprintf(stderr, "[vt pin] pool buffer [%p, %p) registered\n", ptr, (void*)((char*)ptr + bytes));
+    PinnedScope::say("[vt pin] pool buffer [%p, %p) registered\n", ptr, (void*)((char*)ptr + bytes));
     return 0;
 }
 
@@ -1823,7 +1863,7 @@ int vt_host_unregister(int dev, void* ptr)
     int rc = use_device(dev);
     if (rc) return rc;
     VT_HIP(hipHostUnregister(ptr));
-    if (std::getenv("VT_DEBUG_PIN")) std::fprintf(stderr, "[vt pin] pool buffer %p released\n", ptr);
+    PinnedScope::say("[vt pin] pool buffer %p released\n", ptr);
     return 0;
 }
 
