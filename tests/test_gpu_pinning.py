@@ -7,7 +7,7 @@ whole 2 MiB units INSIDE the array, and a copy is cut at the ends of that interi
 head and tail travel pageable).  Held here:
   * arrays at every kind of misalignment against the 2 MiB grid, as sources (create, one-shot) and as `output=`: results bit for bit
     (`vt_volume_create` / `vt_volume_affine` / `vt_affine_oneshot` / `vt_volume_upload_planes` all go through the cut copies);
-  * the scenario of round 4's fault on today's layout -- a long-lived registered pooled result, caller arrays of 8 MiB and more inside the
+  * the scenario of round 4's fault on today's layout -- a long-lived registered pooled result, caller arrays above the registration threshold (32 MiB) inside the
     SAME huge-page-advised mapping being pinned and released around it, then the pooled buffer written by the GPU again: no fault, right
     data, forty rounds.
   * the mechanism the fault finally traced to (profiles/r05_pin_trace.txt): the runtime serves a pageable transfer of more than 1 MiB by
