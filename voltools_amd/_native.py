@@ -251,9 +251,11 @@ class _HostResultPool:
             phys_mb = 0
         default_mb = min(65536, max(4096, phys_mb // 10))
         self.cap = int(os.environ.get('VT_HOST_POOL_MB', str(default_mb))) << 20
-        # small results are not worth a pool slot (and a 2 MiB-granular one): below the library's own pinning threshold (PinnedScope, 8 MiB)
-        # a result is a plain numpy array, copied through the runtime's staging buffers
-        self.min_bytes = int(os.environ.get('VT_HOST_POOL_MIN_MB', '8')) << 20
+        # Results below 1 MiB are not worth a pool slot (a 2 MiB-granular one): they are plain numpy arrays, copied through the runtime's
+        # staging buffers.  From 1 MiB on a result that is NOT pooled would travel in 512 KiB staged slices (the library never lets the runtime
+        # pin caller memory in place, and never registers anything the process heap could hold: DESIGN.md section 6) -- 100^3: 0.34 ms instead
+        # of 0.12 --, so the pool starts there (round 4 had it at 8 MiB, the then threshold of the library's own in-place pinning).
+        self.min_bytes = int(float(os.environ.get('VT_HOST_POOL_MIN_MB', '1')) * (1 << 20))
         # reference count of a backing array that nobody outside the pool refers to, measured by the scan itself
         # (the entry is built inside the call: a local name for the backing array would count as a holder)
         self._idle = self._scan([self._new_entry(1)], 1, calibrate=True)
