@@ -280,7 +280,11 @@ bool quad_pick_tile(PlanCtx& c, int64_t max_stride)
     // [measured, one variant per process, profiles/r03_process_ab.txt] 512^3 sweep 0.1924 -> 0.1876 ms on average (each form is bimodal
     // by 2 % from process to process), 1024^3 1.471 -> 1.482 (stays on 16 x 32); the cubic kernel at 512^3 loses 3 % with it.
     int order[8], norder = 0;
-    const bool big_cubic = c.cubic && (int64_t)v->H * v->W > 512LL * 512;
+    // (Round 5: not the one-tap-plane cubic kernel, KIND 4 -- [measured, one process per variant, three alternations, three boxes] 1024^3
+    //  filt_bspline sweep 1.508 / 1.509 / 1.510 ms on the 16 x 32 tile against 1.538 / 1.524 / 1.524 on 32 x 32 x 512 (1.3 %, the same sign in
+    //  nine of nine pairs), 768^3 equal: its 30 KB of LDS keep four workgroups per CU.  The four-plane kernel keeps the preference.)
+    const bool zfir_k4 = c.cubic && (float)(c.m[3] - std::floor(c.m[3])) == 0.0f && v->tune.quad_zfir != 0 && !(c.flags & VT_NO_ZFIR);
+    const bool big_cubic = c.cubic && !zfir_k4 && (int64_t)v->H * v->W > 512LL * 512;
     const bool lin_zid = !c.cubic && (float)(c.m[3] - std::floor(c.m[3])) == 0.0f && v->tune.quad_zid != 0;
     const bool mid_linear = lin_zid && (int64_t)v->H * v->W <= 512LL * 512 && (int64_t)v->oD * v->oH * v->oW >= 384LL * 384 * 384;
     // ... and on larger planes the 16 x 64 tile with 512 threads (256-byte store rows): 1024^3 sweep 1.551 -> 1.529 ms (32 x 32: 1.482 vs
