@@ -63,7 +63,7 @@ enum vt_flags {
     VT_NO_ZFIR = 16384,    /* diagnostic: cubic plane-quad launches with an integer axis-0 offset keep the four-tap-plane kernel
                               instead of sampling the z-convolved copy (also what a call falls back to when that copy does not fit) */
     VT_NO_REORIENT = 32768,/* diagnostic: general matrices always sample the plain resident copy, never an axis-permuted one */
-    VT_NO_ROWS = 65536     /* diagnostic: maps that leave axis 2 alone take the axis-exchange path, not the row kernel (kind 7) */
+    VT_NO_ROWS = 65536     /* diagnostic: maps that leave axis 2 alone take the axis-exchange path, not the row kernel (kind 10) */
 };
 
 /* flags for vt_volume_create* */

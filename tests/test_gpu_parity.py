@@ -1066,23 +1066,30 @@ def test_reoriented_copies_are_built_at_the_fourth_request_only():
     sv.close()
 
 
+@pytest.mark.parametrize('cubic_frac', [False, True], ids=['default', 'VT_ROWS=2'])
 @pytest.mark.parametrize('interp', ALL_INTERPS)
 @pytest.mark.parametrize('shape', [(70, 66, 72), (33, 47, 50), (5, 9, 130), (64, 64, 64)])
-def test_row_kernel_for_maps_that_leave_axis_2_alone(interp, shape):
+def test_row_kernel_for_maps_that_leave_axis_2_alone(interp, shape, cubic_frac, monkeypatch):
     """Kind 10 (vt_kernels_rows.hip): rotations about axis 2 and any (d, h) affine map with any axis-2 offset.  Against the oracle at the
     family's tolerance and BIT-IDENTICAL to affine_direct (same chain of operations; for integer offsets the x-sum of the cubic stencil is
-    formed once in the x-convolved copy); widths that are no multiple of 64 or 4, offsets that push rows over either end, keep_outside."""
+    formed once in the x-convolved copy); widths that are no multiple of 64 or 4, offsets that push rows over either end, keep_outside.
+    Cubic launches with a FRACTIONAL offset take the row kernel only under VT_ROWS=2 (64 taps per voxel from the plain copy: measured
+    slower than the exchange path, vt_plan.hip::plan_rows); the second parametrisation holds that form to the same bits."""
+    if cubic_frac:
+        if interp == 'linear':
+            pytest.skip('the knob changes cubic launches only')
+        monkeypatch.setenv('VT_ROWS', '2')
+    slow_frac = interp != 'linear' and not cubic_frac
     vol = rand_vol(shape, 51)
     c = centre(shape)
     rot = vt.utils.transform_matrix(rotation=(0, 0, 33), rotation_order='sxyz', center=c)
     cases = {'rot33': (rot, True)}
-    # (round 5: every axis-2 offset takes the row kernel -- integers that are no multiple of four stage 18 vectors per row instead of 16,
-    #  fractional ones add the x taps of the interpolation, on the plain copy for cubic: /root/reference/voltools/transforms.py:269-281 has
-    #  no cliff there either)
+    # (round 5: integers that are no multiple of four stage 18 vectors per row instead of 16; fractional offsets add the x taps of the
+    #  interpolation -- trilinear always, cubic on request)
     for name, t2, takes in (('rot33_w+8', 8.0, True), ('rot33_w-4', -4.0, True), ('rot33_w+2', 2.0, True), ('rot33_w+0.5', 0.5, True),
                             ('rot33_w-3', -3.0, True), ('rot33_w+1.25', 1.25, True), ('rot33_w-7.75', -7.75, True), ('rot33_w+61', 61.0, True)):
         m = rot.copy(); m[2, 3] += t2
-        cases[name] = (m, takes)
+        cases[name] = (m, takes and not (slow_frac and t2 != np.floor(t2)))
     m = vt.utils.transform_matrix(rotation=(0, 0, -100), scale=(1.2, 0.8, 1.0), translation=(1.5, -2.25, 0.0), rotation_order='sxyz', center=c)
     cases['rot_scale_dh'] = (m, True)
     m = vt.utils.transform_matrix(rotation=(0, 0, 200), rotation_order='sxyz', center=c); m[2, 3] = float(shape[2] - 4 - (shape[2] % 4))
@@ -1175,6 +1182,7 @@ def test_row_kernel_with_two_row_buffers_returns_the_same_bits(interp, monkeypat
         m = rot.copy(); m[2, 3] += t2
         mats.append(m)
     got = {}
+    monkeypatch.setenv('VT_ROWS', '2')                      # (cubic launches with fractional offsets on the row kernel too)
     for db in ('0', '1'):
         monkeypatch.setenv('VT_ROWS_DB', db)
         sv = vt.StaticVolume(vol, interpolation=interp, device='gpu:0')

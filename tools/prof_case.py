@@ -21,6 +21,7 @@ ap.add_argument('--sweep', type=float, default=0.0, help='README sweep: rotate((
 ap.add_argument('--general', action='store_true', help='general 3-D rotation (25,-40,70) sxyz instead of in-plane')
 ap.add_argument('--case', default='', help='named matrix from tests/test_gpu_parity.py MATRICES (overrides --angle/--general)')
 ap.add_argument('--random100', action='store_true', help="the 100 random sxyz rotations of the reference's protocol (tests/benchmark.py:52-54), one after the other")
+ap.add_argument('--shift2', type=float, default=0.0, help='added to the axis-2 offset of the matrix (row kernel: integer / fractional offsets)')
 ap.add_argument('--iters', type=int, default=10)
 ap.add_argument('--flags', type=int, default=0)
 args = ap.parse_args()
@@ -43,6 +44,7 @@ if args.axis1:
     m = vt.utils.transform_matrix(rotation=(0, args.angle, 0), rotation_order='sxyz', center=c)
 if args.axis2:
     m = vt.utils.transform_matrix(rotation=(0, 0, args.angle), rotation_order='sxyz', center=c)
+    m[2, 3] += args.shift2
 if args.case:
     import os, sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))

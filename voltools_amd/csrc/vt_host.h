@@ -38,7 +38,7 @@ struct Tuning {
     int rows_pd = 8;               // VT_ROWS_PD=4: the row kernel's pixel tile is 4 x 8 (four waves) instead of 8 x 8
     int no_fused_relayout = 0;     // VT_NO_FUSED_RELAYOUT=1: the plane-quad forms of the in-plane transposed orientation through an exchanged plain copy (rounds 2-4) instead of relayout_zquad_swap12
     int rows_db = 0;               // VT_ROWS_DB: 0 = one run per workgroup (the default: faster), 1 = the row kernel walks a tile's runs with two row buffers where they fit, 2 = the same on the 4 x 8 tile
-    int rows = 1;                  // VT_ROWS=0: maps that leave axis 2 alone take the axis-exchange path instead of the row kernel (kind 10)
+    int rows = 1;                  // VT_ROWS=0: maps that leave axis 2 alone take the axis-exchange path instead of the row kernel (kind 10); 2: the row kernel also for cubic launches with a fractional axis-2 offset (slower than the exchange path: tests only)
     int quad_zfir = 1;             // VT_QUAD_ZFIR=0: cubic launches with fz == 0 keep the four-plane kernel (round-4 A/B: the z-convolved copy)
     int zid_dch = 0;               // VT_ZID_DCH: chunk depth of the integer-offset trilinear kernel (0 = the trilinear default)
     int quad_nt = -1;              // VT_QUAD_NT: 1 / 0 = nontemporal / plain output stores of the plane-quad kernel, -1 = planner's choice

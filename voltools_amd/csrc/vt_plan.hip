@@ -1112,6 +1112,12 @@ bool plan_rows(const vt_volume* v, const double m[12], int flags, AffineParams* 
     const double tfl = std::floor(t);
     const bool frac = t != tfl;
     const int nv = (!frac && ((int64_t)tfl & 3) == 0) ? 16 : 18;
+    // ... except cubic with a FRACTIONAL offset, which stays with the exchange path unless asked for (VT_ROWS=2, the parity tests): its 64
+    // taps per voxel from the plain copy are [measured, 512^3, one box, one process per case, tools/diag/rows_shift_ab.sh] 0.594 / 0.610 ms at
+    // 33 / 80 degrees against 0.440 / 0.439 for exchanged copy + plane-quad kernel + transpose pass.  (Integer offsets: 0.328 / 0.303 at a
+    // multiple of four, 0.368 / 0.327 at t = 2, against 0.424 / 0.421; trilinear 0.219 / 0.221, 0.260 / 0.243 at t = 2, 0.277 / 0.261 at t = 0.5,
+    // against 0.32-0.34 for the bounding-box kernel.)
+    if (frac && is_cubic(v->interp) && v->tune.rows != 2) return false;
     for (int i = 0; i < 12; ++i) if (!(std::fabs(m[i]) < 1.0e9)) return false;
     int ph, run;
     rows_tile(&ph, &run);
