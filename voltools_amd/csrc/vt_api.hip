@@ -398,12 +398,6 @@ struct PinnedScope {
         lo = reinterpret_cast<char*>(a0);
         hi = reinterpret_cast<char*>(a1);
     }
-    // is [h, h + n) memory the runtime treats as pinned (our interior, or a range somebody registered: the pool's buffers)?
-    bool is_pinned_range(const char* h, size_t n) const
-    {
-        if (pinned && h >= lo && h + n <= hi) return true;
-        return already_registered(h);
-    }
     // one pageable piece, in slices the runtime stages (rule 1)
     static hipError_t sliced(char* dst, const char* src, size_t bytes, hipMemcpyKind kind, hipStream_t st)
     {
