@@ -1035,6 +1035,16 @@ bool plan_general(PlanCtx& c)
     const bool have_box = pick_box_tile(c, &box_bpv);
     if (plan_packed(c, have_box, box_bpv)) return true;
     if (!have_box) return false;
+    // Strong minification: a tile's bounding box grows with the cube of the scale while most of the output maps outside the volume.  Where
+    // the box leaves one workgroup per CU, or (trilinear) stages more than ~43 bytes per voxel, the direct kernel's gather through the
+    // caches is faster -- [measured, 512^3, tools/diag/magnify_ab.py -> profiles/r05_minification_routing.txt] trilinear scale 2.25 / 2.5 / 3:
+    // boxes 0.403 / 0.516 / 0.919 ms against 0.372 / 0.369 / 0.352; cubic scale 2.5 / 3: 1.10 / 1.15 against 0.63 / 0.55; the one case
+    // measured the other way is a cubic in-plane rotation at scale 2 (2.01 against 2.26 ms).  VT_FORCE_TILED keeps the boxes.
+    if (c.plan->kind == 2 && !(c.flags & VT_FORCE_TILED) && c.v->tune.tile < 0 &&
+        (c.plan->lds_bytes > 80 * 1024 || (!c.cubic && box_bpv > 43.0))) {
+        c.plan->kind = 1; c.plan->cfg = -1; c.plan->td = c.plan->th = c.plan->tw = 0; c.plan->lds_bytes = 0; c.plan->grid = 0;
+        return true;
+    }
     if (!finish_box(c)) { c.plan->kind = 1; }
     return true;
 }
