@@ -1040,7 +1040,12 @@ bool plan_general(PlanCtx& c)
     // caches is faster -- [measured, 512^3, tools/diag/magnify_ab.py -> profiles/r05_minification_routing.txt] trilinear scale 2.25 / 2.5 / 3:
     // boxes 0.403 / 0.516 / 0.919 ms against 0.372 / 0.369 / 0.352; cubic scale 2.5 / 3: 1.10 / 1.15 against 0.63 / 0.55; the one case
     // measured the other way is a cubic in-plane rotation at scale 2 (2.01 against 2.26 ms).  VT_FORCE_TILED keeps the boxes.
-    if (c.plan->kind == 2 && !(c.flags & VT_FORCE_TILED) && c.v->tune.tile < 0 &&
+    // Only where the map shrinks the volume to a ninth or less (|det| >= 9: nearly all of the output lies outside, which is what makes the
+    // direct kernel cheap): a mild minification with a rotation -- scale 1.2, rotation (10, 20, 30): a box of more than 80 KB, 58 % of the
+    // output inside -- takes 6.3 ms on the direct kernel (cubic, 512^3) and stays with the boxes.
+    const double* mm = c.m;
+    const double det = mm[0] * (mm[5] * mm[10] - mm[6] * mm[9]) - mm[1] * (mm[4] * mm[10] - mm[6] * mm[8]) + mm[2] * (mm[4] * mm[9] - mm[5] * mm[8]);
+    if (c.plan->kind == 2 && !(c.flags & VT_FORCE_TILED) && c.v->tune.tile < 0 && std::fabs(det) >= 9.0 &&
         (c.plan->lds_bytes > 80 * 1024 || (!c.cubic && box_bpv > 43.0))) {
         c.plan->kind = 1; c.plan->cfg = -1; c.plan->td = c.plan->th = c.plan->tw = 0; c.plan->lds_bytes = 0; c.plan->grid = 0;
         return true;
